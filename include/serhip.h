@@ -1,0 +1,136 @@
+/*
+ * serhip.h -- C ABI of libserhip.so, the MI355X (gfx950) implementation of the
+ * jsugg/ser fast-profile acoustic feature path.
+ *
+ * The reference has no native ABI; its seam is a set of Python callables
+ * (SURVEY.md section 8b).  Every entry point below names the reference
+ * interface (file:line under /root/reference) whose arithmetic it replaces.
+ * The Python package ser_amd binds these with ctypes (ser_amd/_native.py) and
+ * re-exposes the reference's own signatures on top.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SERHIP_E_* code;
+ *     serhip_last_error() then holds a thread-local message.  No exceptions
+ *     cross the boundary.
+ *   - "dev" pointers are device (HBM) pointers on the context's GPU; "host"
+ *     pointers are ordinary host memory.  The caller owns all buffers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Work is enqueued asynchronously; outputs are valid once the stream has
+ *     been synchronised.  Host descriptor arrays may be reused as soon as the
+ *     call returns.
+ *   - a serhip_ctx is bound to one device and is not thread-safe; distinct
+ *     contexts are independent.  Handles are opaque.
+ */
+#ifndef SERHIP_H
+#define SERHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SERHIP_OK 0
+#define SERHIP_E_INVALID (-1)   /* bad argument (NULL, range, shape)            */
+#define SERHIP_E_HIP (-2)       /* a HIP runtime call failed                    */
+#define SERHIP_E_NOMEM (-3)     /* workspace allocation failed                  */
+#define SERHIP_E_UNSUPPORTED (-4) /* valid request outside the implemented path */
+
+/* Feature-group bits; order of the output blocks is fixed: mfcc | chroma | mel |
+ * contrast, as in ser/_internal/utils/dsp.py:106-151 and
+ * ser/_internal/repr/handcrafted.py:45-59 (FeatureFlags, config/schema.py:219-227).
+ * Tonnetz (6 dims) is outside the path. */
+#define SERHIP_FEAT_MFCC 1u      /* 40 dims */
+#define SERHIP_FEAT_CHROMA 2u    /* 12 dims */
+#define SERHIP_FEAT_MEL 4u       /* 128 dims */
+#define SERHIP_FEAT_CONTRAST 8u  /* 7 dims (identically 0: reference quirk) */
+
+typedef struct serhip_ctx serhip_ctx;
+typedef struct serhip_plan serhip_plan;
+
+/* Library / ABI version (major*10000 + minor*100 + patch). */
+int serhip_version(void);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* serhip_last_error(void);
+
+/* Create / destroy a context bound to HIP device `device_id`.
+ * No reference counterpart (the reference runs on the host). */
+int serhip_create(int device_id, serhip_ctx** out);
+void serhip_destroy(serhip_ctx* ctx);
+
+/* Build the constant tables (periodic Hann window, FFT twiddles, Slaney mel
+ * filterbank, the 101 chroma filterbanks one per possible tuning estimate,
+ * ortho DCT-II) for one sample rate and upload them.
+ * Replaces the per-call table construction inside librosa that
+ * ser/_internal/utils/dsp.py:100-136 triggers (filters.mel, filters.chroma,
+ * get_window, scipy.fft.dct), done once per (sample_rate, flags). */
+int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, serhip_plan** out);
+void serhip_plan_destroy(serhip_plan* plan);
+
+/* Output width D of a plan: 40*mfcc + 12*chroma + 128*mel + 7*contrast
+ * (HandcraftedBackend.feature_dim, repr/handcrafted.py:45-59). */
+int serhip_plan_feature_dim(const serhip_plan* plan);
+
+/* THE HOT PATH.  One feature vector per segment:
+ *   out_dev[i, :] = extract_feature_from_signal(audio[seg_offset[i] : seg_offset[i]+seg_len[i]], sr)
+ * i.e. ser/_internal/utils/dsp.py:67-151 (pad to >=512 samples, n_fft = min(N, 2048),
+ * STFT, mel / log-mel+DCT MFCC / tuning-corrected chroma / contrast, time-mean), batched
+ * over `n_seg` independent segments that may overlap in `audio_dev` (sliding windows of
+ * HandcraftedBackend.encode_sequence, repr/handcrafted.py:85-97, need no copies).
+ *   audio_dev   device, f32 mono samples, finite (the caller validates, dsp.py:94-95)
+ *   n_audio     number of samples in audio_dev; every segment must lie inside it
+ *   seg_offset  host, [n_seg] first sample of each segment
+ *   seg_len     host, [n_seg] samples per segment, >= 1
+ *   out_dev     device, [n_seg, D] row-major f32
+ *   tuning_dev  device, [n_seg] f32 chroma tuning estimate per segment, or NULL
+ * Segments with >= 2048 samples run the LDS-staged radix FFT kernels; shorter ones
+ * (n_fft = N, any integer 512..2047) run a direct double-precision DFT kernel. */
+int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_audio,
+                         const int64_t* seg_offset, const int64_t* seg_len, int64_t n_seg,
+                         float* out_dev, float* tuning_dev, void* stream);
+
+/* Segment statistics pooling over contiguous frame ranges [win_lo[i], win_hi[i]):
+ *   mode 0: out[i] = [mean | population std] in float64, width 2*D
+ *           (mean_std_pool, ser/_internal/pool/stats_pool.py:15-43)
+ *   mode 1: out[i] = mean accumulated in float32 then widened, width D
+ *           (HandcraftedBackend.pool, repr/handcrafted.py:109-122)
+ * The ranges are what overlap_frame_mask (repr/backend.py:81-111) selects for
+ * non-decreasing frame times; the host computes them.
+ *   emb_dev  device, [n_frames, dim] row-major f32
+ *   win_lo/win_hi host, [n_win] int32, 0 <= lo < hi <= n_frames
+ *   out_dev  device, [n_win, 2*dim] (mode 0) or [n_win, dim] (mode 1) float64 */
+int serhip_pool_windows(serhip_ctx* ctx, const float* emb_dev, int32_t n_frames, int32_t dim,
+                        const int32_t* win_lo, const int32_t* win_hi, int32_t n_win, int mode,
+                        double* out_dev, void* stream);
+
+/* Whisper-style log-mel front end of the transcript lane:
+ *   whisper.audio.log_mel_spectrogram(audio, n_mels, padding=0)
+ * (called at ser/_internal/transcript/backends/stable_whisper_mps_compat.py:192-201):
+ * reflect-padded STFT n_fft 400 / hop 160 / periodic Hann, last frame dropped, |X|^2,
+ * Slaney mel (16 kHz), log10(max(.,1e-10)), clamp to max-8 per clip, (x+4)/4.
+ *   audio_dev device, [n_clips, n_samples] f32 (each clip processed independently)
+ *   out_dev   device, [n_clips, n_mels, n_samples/160] f32 (integer division: torch.stft
+ *             yields 1 + n_samples/160 columns and whisper drops the last)
+ * n_mels is 80 or 128; n_samples must be > 200 (reflect padding of 200 per side). */
+int serhip_whisper_logmel(serhip_ctx* ctx, const float* audio_dev, int32_t n_clips,
+                          int64_t n_samples, int32_t n_mels, float* out_dev, void* stream);
+
+/* ---- host-only helpers (no GPU touched; used by the CPU test-suite) ---- */
+
+/* Copy one host-built constant table of the fast plan into `out` (f32).
+ *   which: 0 window[2048]   1 mel filterbank [128,1025]   2 chroma filterbank for
+ *          tuning index `arg` (0..100) [12,1025]   3 DCT [40,128]
+ *          4 piptrack bin range {kmin,kmax} as 2 floats
+ * Returns the element count written (or needed if out is NULL), <0 on error. */
+int64_t serhip_host_table(int sample_rate, int which, int arg, float* out, int64_t out_cap);
+
+/* Frame bookkeeping of the STFT used by every kernel: number of STFT columns
+ * for a segment of n_samples (after the >=512 padding) -- librosa.stft center=True,
+ * hop 512 for n_fft 2048.  Exposed so hosts can size buffers / tests can pin it. */
+int64_t serhip_frame_count(int64_t n_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SERHIP_H */

@@ -1,0 +1,584 @@
+// gfx950 kernels of the fast feature path (segments with >= 2048 samples, n_fft = 2048,
+// hop 512) -- the GPU form of ser/_internal/utils/dsp.py:96-136.
+//
+//   k_stft_frames   one wave64 per STFT frame: framing + Hann + 2048-pt real FFT
+//                   (1024-pt complex, radix 16 x 16 x 4, two LDS transposes, the
+//                   radix-4 across quads with DPP), |X| and |X|^2, sparse Slaney mel
+//                   projection, piptrack peak picking.  Writes per frame: magnitudes,
+//                   128 mel powers, the (pitch, mag) peak list.
+//   k_segment_finish one workgroup per segment: log-mel clip/mean -> DCT (MFCC), mel
+//                   mean, tuning estimate (median select + 100-bin histogram), chroma
+//                   projection with the selected filterbank, inf-norm, time mean.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "fft_math.hpp"
+#include "tables.hpp"
+
+namespace serhip {
+
+constexpr int kWaves = 4;              // waves per workgroup in k_stft_frames
+constexpr int kFramesPerBlock = 16;    // STFT frames per workgroup
+constexpr int kBufC = 1088;            // complex slots of one wave's LDS buffer (16 rows x stride 68)
+constexpr int kMelWCap = 2304;         // capacity of the sparse mel weight stream
+constexpr int kPeakLdsCap = 6144;      // peaks staged in LDS by k_segment_finish
+
+// per-segment descriptor (device copy of what the host planned)
+struct SegDesc {
+    long long offset;     // first sample in the audio buffer
+    long long out_row;    // row of the output matrix
+    int len;              // samples in the segment (before the >=512 zero padding)
+    int n_fft;            // 2048 on the fast path, max(len,512) on the generic path
+    int n_stft;           // STFT columns (hop n_fft/4)
+    int n_mel;            // mel-STFT columns (hop 512)
+    int stft_base;        // first row in the magnitude / peak scratch
+    int mel_base;         // first row in the mel scratch
+};
+
+// constant tables of one plan (device pointers)
+struct PlanTables {
+    const v2f* twA;       // [16][64]  W_1024^(lane*k1)
+    const v2f* twB;       // [16][4]   W_64^(m2*j1)
+    const v2f* twU;       // [8][64]   W_2048^(lane+64r)
+    const v2f* win;       // [16][64]  Hann pairs (w[128n1+2l], w[128n1+2l+1])
+    const float* mel_w;   // sparse mel weights, filter-major
+    const int4* mel_rng;  // [128] (first bin, count, offset into mel_w, 0)
+    const float* chroma;  // [101][12][kBinStride]
+    const float* dct;     // [40][128]
+    const double* edges;  // [101] histogram edges np.linspace(-0.5, 0.5, 101)
+    const double* mel_f;  // [130] mel band edges in Hz (generic path)
+    int mel_nnz;
+    int kmin, kmax;       // piptrack bin range (inclusive) for n_fft 2048
+    int sample_rate;
+    unsigned flags;
+};
+
+// per-chunk scratch (device pointers)
+struct Scratch {
+    float* mags;          // [frames][kBinStride]
+    float* mel;           // [frames][128]
+    v2f* peaks;           // [frames][peak_cap]  (pitch, mag)
+    int* peak_cnt;        // [frames]
+    int peak_cap;         // peak slots per frame
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+
+// make this wave's LDS writes visible to its own later reads (one wave owns the buffer)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// piptrack arithmetic for one local maximum (librosa.piptrack, called from estimate_tuning
+// inside chroma_stft; dsp.py:115).  sm/s0/sp = S[i-1], S[i], S[i+1] (f32 magnitudes).
+// The parabolic shift is a double division of float32 sums, as numba evaluates the stencil.
+__device__ __forceinline__ v2f piptrack_peak(float sm, float s0, float sp, int i, double bin_hz_num,
+                                             double n_fft_d) {
+    const float sum = sp + sm;
+    const float dif = sp - sm;
+    const double a = static_cast<double>(sum) - 2.0 * static_cast<double>(s0);
+    const double b = static_cast<double>(dif) / 2.0;
+    float shift = 0.0f;
+    if (!(fabs(b) >= fabs(a))) shift = static_cast<float>(-b / a);
+    const float avg = dif / 2.0f;                 // np.gradient interior point, f32
+    const float dskew = __fmul_rn(0.5f * avg, shift);   // separately rounded, as numpy does
+    const double pitch = (static_cast<double>(i) + static_cast<double>(shift)) * bin_hz_num / n_fft_d;
+    return v2f{static_cast<float>(pitch), __fadd_rn(s0, dskew)};
+}
+
+// ---------------------------------------------------------------------------------------
+// k_stft_frames
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __restrict__ audio,
+                                                             const SegDesc* __restrict__ segs,
+                                                             PlanTables tb, Scratch sc) {
+    __shared__ v2f s_twA[16 * 64];
+    __shared__ v2f s_twU[8 * 64];
+    __shared__ v2f s_win[16 * 64];
+    __shared__ v2f s_twB[16 * 4];
+    __shared__ float s_melw[kMelWCap];
+    __shared__ v2f s_buf[kWaves][kBufC];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const SegDesc sd = segs[blockIdx.y];
+    const int t_begin = blockIdx.x * kFramesPerBlock;
+    if (t_begin >= sd.n_stft) return;  // whole workgroup leaves before any barrier
+
+    for (int i = tid; i < 16 * 64; i += kWaves * 64) {
+        s_twA[i] = tb.twA[i];
+        s_win[i] = tb.win[i];
+    }
+    for (int i = tid; i < 8 * 64; i += kWaves * 64) s_twU[i] = tb.twU[i];
+    if (tid < 64) s_twB[tid] = tb.twB[tid];
+    for (int i = tid; i < tb.mel_nnz; i += kWaves * 64) s_melw[i] = tb.mel_w[i];
+    __syncthreads();
+
+    v2f* buf = s_buf[wave];
+    float* fbuf = reinterpret_cast<float*>(buf);
+    float* sP = fbuf;            // power, bins 0..1024
+    float* sM = fbuf + 1032;     // magnitude, bins 0..1024
+
+    const float* seg_audio = audio + sd.offset;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(seg_audio) & 7u) == 0);
+    const int4 rng0 = tb.mel_rng[lane];
+    const int4 rng1 = tb.mel_rng[127 - lane];
+    const int q = lane & 3;
+    const float sg1 = (q & 2) ? -1.0f : 1.0f;
+    const float sg2 = (q & 1) ? -1.0f : 1.0f;
+    const int j2 = ((q & 1) << 1) | (q >> 1);
+    const int k1b = lane >> 2;
+    const double sr_d = static_cast<double>(tb.sample_rate);
+    const bool want_chroma = (tb.flags & 2u) != 0;
+    const bool want_mel = (tb.flags & 5u) != 0;
+
+    const int t_end = min(t_begin + kFramesPerBlock, sd.n_stft);
+    for (int t = t_begin + wave; t < t_end; t += kWaves) {
+        // ---- framing + window: frame t covers segment samples [t*512 - 1024, t*512 + 1024)
+        const long long fs = static_cast<long long>(t) * kHop - kNfft / 2;
+        v2f v[16];
+        if (fs >= 0 && fs + kNfft <= sd.len) {
+            const float* p = seg_audio + fs + 2 * lane;
+            if (aligned) {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) v[n1] = *reinterpret_cast<const v2f*>(p + 128 * n1);
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) v[n1] = v2f{p[128 * n1], p[128 * n1 + 1]};
+            }
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const long long s = fs + 128 * n1 + 2 * lane;
+                const float a = (s >= 0 && s < sd.len) ? seg_audio[s] : 0.0f;
+                const float b = (s + 1 >= 0 && s + 1 < sd.len) ? seg_audio[s + 1] : 0.0f;
+                v[n1] = v2f{a, b};
+            }
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = v[n1] * s_win[n1 * 64 + lane];
+
+        // ---- stage A: 16-pt DFT over n1 (registers), twiddle W_1024^(lane*k1), transpose
+        fft16(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) v[SERHIP_REV4(k1)] = cmul(v[SERHIP_REV4(k1)], s_twA[k1 * 64 + lane]);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) buf[k1 * 68 + lane] = v[SERHIP_REV4(k1)];
+        wave_lds_sync();
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) v[m1] = buf[k1b * 68 + 4 * m1 + q];
+        wave_lds_sync();
+
+        // ---- stage B: 16-pt DFT over m1, twiddle W_64^(m2*j1), radix-4 across the quad
+        fft16(v);
+#pragma unroll
+        for (int j1 = 0; j1 < 16; ++j1) {
+            v2f x = v[SERHIP_REV4(j1)];
+            if (j1 > 0) x = cmul(x, s_twB[j1 * 4 + q]);
+            const v2f p = v2f{dpp_mov<0x4E>(x.x), dpp_mov<0x4E>(x.y)};   // lane ^ 2
+            v2f u = p + sg1 * x;
+            if (q == 3) u = mul_neg_i(u);
+            const v2f p2 = v2f{dpp_mov<0xB1>(u.x), dpp_mov<0xB1>(u.y)};  // lane ^ 1
+            const v2f w = p2 + sg2 * u;
+            // Z[k], k = k1 + 16*j1 + 256*j2, stored at k + 4*(k>>8)
+            buf[k1b + 16 * j1 + 260 * j2] = w;
+        }
+        wave_lds_sync();
+
+        // ---- real-FFT unpack: bins k = lane + 64r and 1024 - k from Z[k], Z[1024-k]
+        float mlo[8], mhi[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = lane + 64 * r;
+            const int kk = (1024 - k) & 1023;
+            const v2f za = buf[k + 4 * (r >> 2)];
+            const v2f zb = buf[kk + 4 * (kk >> 8)];
+            const v2f e2 = v2f{za.x + zb.x, za.y - zb.y};       // 2E
+            const v2f o2 = v2f{za.y + zb.y, zb.x - za.x};       // 2O
+            const v2f t2 = cmul(o2, s_twU[r * 64 + lane]);
+            const v2f xlo = 0.5f * (e2 + t2);
+            const v2f xhi = 0.5f * (e2 - t2);
+            mlo[r] = sqrtf(xlo.x * xlo.x + xlo.y * xlo.y);
+            mhi[r] = sqrtf(xhi.x * xhi.x + xhi.y * xhi.y);
+        }
+        float m512 = 0.0f;
+        if (lane == 0) {
+            const v2f z = buf[512 + 8];
+            m512 = sqrtf(z.x * z.x + z.y * z.y);
+        }
+        wave_lds_sync();  // every lane has read Z before the buffer is reused
+
+        const size_t row = static_cast<size_t>(sd.stft_base) + t;
+        float cmax = m512;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = lane + 64 * r;
+            sM[k] = mlo[r];
+            sM[1024 - k] = mhi[r];
+            sP[k] = mlo[r] * mlo[r];
+            sP[1024 - k] = mhi[r] * mhi[r];
+            cmax = fmaxf(cmax, fmaxf(mlo[r], mhi[r]));
+        }
+        if (lane == 0) {
+            sM[512] = m512;
+            sP[512] = m512 * m512;
+        }
+        if (want_chroma) {
+            float* mrow = sc.mags + row * kBinStride;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = lane + 64 * r;
+                mrow[k] = mlo[r];
+                mrow[1024 - k] = mhi[r];
+            }
+            if (lane == 0) mrow[512] = m512;
+        }
+        wave_lds_sync();
+
+        // ---- sparse Slaney mel projection: lane owns filters `lane` and `127 - lane`
+        if (want_mel) {
+            float acc0 = 0.0f, acc1 = 0.0f;
+            const int n0 = rng0.y, n1c = rng1.y;
+            const int nmax = max(n0, n1c);
+            for (int j = 0; j < nmax; ++j) {
+                if (j < n0) acc0 = fmaf(s_melw[rng0.z + j], sP[rng0.x + j], acc0);
+                if (j < n1c) acc1 = fmaf(s_melw[rng1.z + j], sP[rng1.x + j], acc1);
+            }
+            float* melrow = sc.mel + (static_cast<size_t>(sd.mel_base) + t) * kMels;
+            melrow[lane] = acc0;
+            melrow[127 - lane] = acc1;
+        }
+
+        // ---- piptrack peaks (bins kmin..kmax), threshold 0.1 * column max
+        if (want_chroma) {
+            cmax = wave_max(cmax);
+            const float ref = 0.1f * cmax;
+            v2f* prow = sc.peaks + row * sc.peak_cap;
+            int base = 0;
+            for (int r = 0; 64 * r <= tb.kmax; ++r) {
+                const int k = lane + 64 * r;
+                bool is_peak = false;
+                float sm = 0.f, s0 = 0.f, sp = 0.f;
+                if (k >= tb.kmin && k <= tb.kmax) {
+                    sm = sM[k - 1];
+                    s0 = sM[k];
+                    sp = sM[k + 1];
+                    const float tm = sm > ref ? sm : 0.0f;
+                    const float t0 = s0 > ref ? s0 : 0.0f;
+                    const float tp = sp > ref ? sp : 0.0f;
+                    is_peak = (t0 > tm) && (t0 >= tp);
+                }
+                const unsigned long long mask = __ballot(is_peak);
+                if (is_peak) {
+                    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    prow[pos] = piptrack_peak(sm, s0, sp, k, sr_d, static_cast<double>(kNfft));
+                }
+                base += __popcll(mask);
+            }
+            if (lane == 0) sc.peak_cnt[row] = base;
+        }
+        wave_lds_sync();  // sP / sM reads done before the next frame overwrites the buffer
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_segment_finish helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned float_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// semitone residual of librosa.pitch_tuning in float32: mod(12*log2(f/27.5), 1), folded to
+// [-0.5, 0.5).  log2 is evaluated in double and rounded once (correctly rounded f32 log2).
+__device__ __forceinline__ float tuning_residual(float pitch) {
+    const float qv = pitch / 27.5f;
+    const float o = static_cast<float>(log2(static_cast<double>(qv)));
+    const float v = 12.0f * o;
+    float r = v - floorf(v);
+    if (r >= 0.5f) r -= 1.0f;
+    return r;
+}
+
+// histogram bin of np.histogram(residual, np.linspace(-0.5, 0.5, 101)): [e_i, e_i+1), last closed
+__device__ __forceinline__ int tuning_bin(float r, const double* __restrict__ edges) {
+    const double x = static_cast<double>(r);
+    int i = static_cast<int>((x + 0.5) * 100.0);
+    i = max(0, min(99, i));
+    while (i > 0 && x < edges[i]) --i;
+    while (i < 99 && x >= edges[i + 1]) ++i;
+    return i;
+}
+
+struct FinishShared {
+    float fb[kChroma * kBinStride];   // chroma filterbank of the selected tuning
+    v2f peaks[kPeakLdsCap];
+    unsigned hist[256];
+    float red[64];
+    int ired[8];
+    float lmean[kMels];
+    float melsum[2][kMels];
+    float lsum[2][kMels];
+    float chroma_acc[4][16];
+    unsigned sel_prefix, sel_k;
+    int n_peaks;
+    int tuning_idx;
+    float thr;
+};
+
+// iterate over all peaks of the segment; F is called as f(pitch_mag)
+template <typename F>
+__device__ __forceinline__ void for_each_peak(const FinishShared& sh, bool in_lds, const Scratch& sc,
+                                              const SegDesc& sd, int peak_cap, F f) {
+    if (in_lds) {
+        for (int i = threadIdx.x; i < sh.n_peaks; i += blockDim.x) f(sh.peaks[i]);
+    } else {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (int t = wave; t < sd.n_stft; t += nw) {
+            const size_t row = static_cast<size_t>(sd.stft_base) + t;
+            const int c = sc.peak_cnt[row];
+            for (int j = lane; j < c; j += 64) f(sc.peaks[row * peak_cap + j]);
+        }
+    }
+}
+
+// k-th smallest peak magnitude (0-based) by 4-pass 8-bit radix select; all threads return it
+__device__ float select_kth(FinishShared& sh, bool in_lds, const Scratch& sc, const SegDesc& sd,
+                            int peak_cap, unsigned k) {
+    unsigned prefix = 0, mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) sh.hist[i] = 0;
+        __syncthreads();
+        for_each_peak(sh, in_lds, sc, sd, peak_cap, [&](v2f pm) {
+            const unsigned key = float_key(pm.y);
+            if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+        });
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned cum = 0;
+            int b = 0;
+            for (; b < 255; ++b) {
+                if (cum + sh.hist[b] > k) break;
+                cum += sh.hist[b];
+            }
+            sh.sel_prefix = prefix | (static_cast<unsigned>(b) << shift);
+            sh.sel_k = k - cum;
+        }
+        __syncthreads();
+        prefix = sh.sel_prefix;
+        k = sh.sel_k;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    return key_float(prefix);
+}
+
+// on-the-fly chroma column for the generic path lives in kernels_generic.hpp
+__device__ void chroma_column_dev(int k, int n_fft, int sr, double tuning, float* out12);
+
+// ---------------------------------------------------------------------------------------
+// k_segment_finish: one workgroup (256 threads) per segment
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_segment_finish(const SegDesc* __restrict__ segs, PlanTables tb,
+                                                        Scratch sc, float* __restrict__ out,
+                                                        float* __restrict__ tuning_out, int out_dim) {
+    __shared__ FinishShared sh;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const SegDesc sd = segs[blockIdx.x];
+    float* orow = out + sd.out_row * out_dim;
+    const bool want_mfcc = tb.flags & 1u, want_chroma = tb.flags & 2u, want_mel = tb.flags & 4u,
+               want_contrast = tb.flags & 8u;
+    const int off_mfcc = 0;
+    const int off_chroma = off_mfcc + (want_mfcc ? kMfcc : 0);
+    const int off_mel = off_chroma + (want_chroma ? kChroma : 0);
+    const int off_contrast = off_mel + (want_mel ? kMels : 0);
+    const int nbins = 1 + sd.n_fft / 2;
+
+    // ---- mel mean and MFCC (power_to_db, top_db=80 vs the segment max, DCT of the time mean)
+    if (want_mfcc || want_mel) {
+        const int m = tid & 127, half = tid >> 7;
+        const float* mel = sc.mel + static_cast<size_t>(sd.mel_base) * kMels;
+        float s = 0.0f, lmax = -INFINITY;
+        for (int t = half; t < sd.n_mel; t += 2) {
+            const float v = mel[static_cast<size_t>(t) * kMels + m];
+            s += v;
+            lmax = fmaxf(lmax, 10.0f * log10f(fmaxf(1e-10f, v)));
+        }
+        sh.melsum[half][m] = s;
+        lmax = wave_max(lmax);
+        if (lane == 0) sh.red[wave] = lmax;
+        __syncthreads();
+        lmax = fmaxf(fmaxf(sh.red[0], sh.red[1]), fmaxf(sh.red[2], sh.red[3]));
+        const float floor_db = lmax - 80.0f;
+        float ls = 0.0f;
+        if (want_mfcc) {
+            for (int t = half; t < sd.n_mel; t += 2) {
+                const float v = mel[static_cast<size_t>(t) * kMels + m];
+                ls += fmaxf(10.0f * log10f(fmaxf(1e-10f, v)), floor_db);
+            }
+        }
+        sh.lsum[half][m] = ls;
+        __syncthreads();
+        const float inv_t = 1.0f / static_cast<float>(sd.n_mel);
+        if (tid < kMels) {
+            sh.lmean[tid] = (sh.lsum[0][tid] + sh.lsum[1][tid]) * inv_t;
+            if (want_mel) orow[off_mel + tid] = (sh.melsum[0][tid] + sh.melsum[1][tid]) * inv_t;
+        }
+        __syncthreads();
+        if (want_mfcc && tid < kMfcc) {
+            float acc = 0.0f;
+            const float* d = tb.dct + tid * kMels;
+            for (int j = 0; j < kMels; ++j) acc = fmaf(d[j], sh.lmean[j], acc);
+            orow[off_mfcc + tid] = acc;
+        }
+    }
+    if (want_contrast && tid < 7) orow[off_contrast + tid] = 0.0f;
+    if (!want_chroma) {
+        if (tuning_out && tid == 0) tuning_out[sd.out_row] = 0.0f;
+        return;
+    }
+
+    // ---- tuning estimate: median of peak magnitudes, histogram of residuals above it
+    if (tid == 0) sh.n_peaks = 0;
+    __syncthreads();
+    int total = 0;
+    for (int t = tid; t < sd.n_stft; t += blockDim.x) total += sc.peak_cnt[static_cast<size_t>(sd.stft_base) + t];
+    total = wave_sum_int(total);
+    if (lane == 0) sh.ired[wave] = total;
+    __syncthreads();
+    const int n_peaks = sh.ired[0] + sh.ired[1] + sh.ired[2] + sh.ired[3];
+    __syncthreads();
+    const bool in_lds = n_peaks <= kPeakLdsCap;
+    if (in_lds) {
+        for (int t = wave; t < sd.n_stft; t += 4) {
+            const size_t row = static_cast<size_t>(sd.stft_base) + t;
+            const int c = sc.peak_cnt[row];
+            if (c == 0) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh.n_peaks, c);
+            base = __shfl(base, 0);
+            for (int j = lane; j < c; j += 64) sh.peaks[base + j] = sc.peaks[row * sc.peak_cap + j];
+        }
+        __syncthreads();
+    } else if (tid == 0) {
+        sh.n_peaks = n_peaks;
+    }
+    int tuning_idx = 50;  // edge 50 is exactly 0.0: librosa's answer for an empty peak set
+    if (n_peaks > 0) {
+        float thr = select_kth(sh, in_lds, sc, sd, sc.peak_cap, static_cast<unsigned>(n_peaks / 2));
+        if ((n_peaks & 1) == 0) {
+            const float lo = select_kth(sh, in_lds, sc, sd, sc.peak_cap, static_cast<unsigned>(n_peaks / 2 - 1));
+            thr = (lo + thr) / 2.0f;  // np.median of an even count: f32 mean of the middle pair
+        }
+        for (int i = tid; i < 256; i += blockDim.x) sh.hist[i] = 0;
+        __syncthreads();
+        for_each_peak(sh, in_lds, sc, sd, sc.peak_cap, [&](v2f pm) {
+            if (pm.y >= thr && pm.x > 0.0f) atomicAdd(&sh.hist[tuning_bin(tuning_residual(pm.x), tb.edges)], 1u);
+        });
+        __syncthreads();
+        if (tid == 0) {
+            unsigned best = 0;
+            int arg = 0;
+            for (int b = 0; b < 100; ++b)
+                if (sh.hist[b] > best) {
+                    best = sh.hist[b];
+                    arg = b;
+                }
+            sh.tuning_idx = arg;
+        }
+        __syncthreads();
+        tuning_idx = sh.tuning_idx;
+    }
+    if (tuning_out && tid == 0) tuning_out[sd.out_row] = static_cast<float>(tb.edges[tuning_idx]);
+
+    // ---- chroma filterbank of that tuning -> LDS
+    if (sd.n_fft == kNfft) {
+        const float4* src = reinterpret_cast<const float4*>(tb.chroma + static_cast<size_t>(tuning_idx) * kChroma * kBinStride);
+        float4* dst = reinterpret_cast<float4*>(sh.fb);
+        for (int i = tid; i < kChroma * kBinStride / 4; i += blockDim.x) dst[i] = src[i];
+    } else {
+        const double tuning = tb.edges[tuning_idx];
+        for (int k = tid; k < nbins; k += blockDim.x) {
+            float col[12];
+            chroma_column_dev(k, sd.n_fft, tb.sample_rate, tuning, col);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) sh.fb[c * kBinStride + k] = col[c];
+        }
+    }
+    __syncthreads();
+
+    // ---- chroma = fb @ |STFT|, per-frame inf-norm, time mean.  Two frames per wave pass.
+    float acc_c = 0.0f;  // lanes 0..11 of each wave accumulate chroma class `lane`
+    const float tiny = 1.17549435e-38f;
+    for (int t0 = 2 * wave; t0 < sd.n_stft; t0 += 8) {
+        const bool two = (t0 + 1) < sd.n_stft;
+        const float* m0 = sc.mags + (static_cast<size_t>(sd.stft_base) + t0) * kBinStride;
+        const float* m1 = two ? m0 + kBinStride : m0;
+        float a0[12], a1[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) a0[c] = a1[c] = 0.0f;
+        for (int k = lane; k < nbins; k += 64) {
+            const float x0 = m0[k], x1 = m1[k];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const float w = sh.fb[c * kBinStride + k];
+                a0[c] = fmaf(w, x0, a0[c]);
+                a1[c] = fmaf(w, x1, a1[c]);
+            }
+        }
+        float mx0 = 0.0f, mx1 = 0.0f, mine0 = 0.0f, mine1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            const float r0 = wave_sum(a0[c]);
+            const float r1 = wave_sum(a1[c]);
+            mx0 = fmaxf(mx0, fabsf(r0));
+            mx1 = fmaxf(mx1, fabsf(r1));
+            if (lane == c) {
+                mine0 = r0;
+                mine1 = r1;
+            }
+        }
+        if (mx0 < tiny) mx0 = 1.0f;
+        if (mx1 < tiny) mx1 = 1.0f;
+        acc_c += mine0 / mx0;
+        if (two) acc_c += mine1 / mx1;
+    }
+    if (lane < 16) sh.chroma_acc[wave][lane] = acc_c;
+    __syncthreads();
+    if (tid < kChroma) {
+        const float s = (sh.chroma_acc[0][tid] + sh.chroma_acc[1][tid]) + (sh.chroma_acc[2][tid] + sh.chroma_acc[3][tid]);
+        orow[off_chroma + tid] = s / static_cast<float>(sd.n_stft);
+    }
+}
+
+}  // namespace serhip

@@ -1,0 +1,187 @@
+// Whisper-style log-mel front end on gfx950 (config 5 of BASELINE.json):
+//   whisper.audio.log_mel_spectrogram(audio, n_mels, padding=0)
+// n_fft 400 / hop 160 / periodic Hann / reflect padding / last frame dropped /
+// Slaney mel at 16 kHz / log10 / clamp to (clip max - 8) / (x + 4) / 4.
+//
+// 400 is not a power of two and may not be zero-padded (the bins would move), so each
+// frame is a 200-point complex DFT of the even/odd packed samples, done as a 25 x 8
+// two-step decomposition through LDS (sums of 25 and 8 terms, so float32 error stays
+// at FFT level), then the real-FFT unpack to 201 bins.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels_fast.hpp"
+
+namespace serhip {
+
+constexpr int kWNfft = 400;
+constexpr int kWHop = 160;
+constexpr int kWBins = 201;
+constexpr int kWHalf = 200;          // packed complex points per frame
+constexpr int kWTile = 64;           // frames per workgroup
+constexpr int kWMelWCap = 1024;      // sparse mel taps (80 mels: ~400, 128 mels: ~500)
+
+struct WhisperTables {
+    const v2f* tw200;    // [200] W_200^m
+    const v2f* tw400;    // [201] W_400^k
+    const float* win;    // [400]
+    const float* mel_w;  // sparse taps
+    const int4* mel_rng; // [n_mels] (first bin, count, offset, 0)
+    int mel_nnz;
+    int n_mels;
+};
+
+// pass 1: log10(max(mel, 1e-10)) into out[clip][m][t] and the running clip maximum
+__global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict__ audio, long long n_samples,
+                                                        int n_frames, WhisperTables wt, float* __restrict__ out,
+                                                        unsigned* __restrict__ clip_max) {
+    __shared__ v2f s_tw200[kWHalf];
+    __shared__ v2f s_tw400[kWBins + 3];
+    __shared__ float s_win[kWNfft];
+    __shared__ float s_melw[kWMelWCap];
+    __shared__ v2f s_z[4][kWHalf];
+    __shared__ v2f s_y[4][kWHalf];
+    __shared__ float s_p[4][kWBins + 3];
+    __shared__ float s_tile[128][kWTile + 1];
+    __shared__ float s_red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int clip = blockIdx.y;
+    const int t_tile = blockIdx.x * kWTile;
+    const float* x = audio + static_cast<size_t>(clip) * n_samples;
+
+    for (int i = tid; i < kWHalf; i += 256) s_tw200[i] = wt.tw200[i];
+    for (int i = tid; i < kWBins; i += 256) s_tw400[i] = wt.tw400[i];
+    for (int i = tid; i < kWNfft; i += 256) s_win[i] = wt.win[i];
+    for (int i = tid; i < wt.mel_nnz; i += 256) s_melw[i] = wt.mel_w[i];
+    __syncthreads();
+
+    const int4 rng0 = (lane < wt.n_mels) ? wt.mel_rng[lane] : int4{0, 0, 0, 0};
+    const int4 rng1 = (lane + 64 < wt.n_mels) ? wt.mel_rng[lane + 64] : int4{0, 0, 0, 0};
+    v2f* z = s_z[wave];
+    v2f* y = s_y[wave];
+    float* p = s_p[wave];
+    float vmax = -INFINITY;
+
+    for (int f = wave; f < kWTile; f += 4) {
+        const int t = t_tile + f;
+        if (t >= n_frames) break;
+        // ---- framing with reflect padding (200 samples each side) + Hann
+        const long long fs = static_cast<long long>(t) * kWHop - kWNfft / 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = lane + 64 * i;
+            if (n < kWHalf) {
+                long long s0 = fs + 2 * n, s1 = s0 + 1;
+                if (s0 < 0) s0 = -s0;
+                if (s0 >= n_samples) s0 = 2 * (n_samples - 1) - s0;
+                if (s1 < 0) s1 = -s1;
+                if (s1 >= n_samples) s1 = 2 * (n_samples - 1) - s1;
+                z[n] = v2f{x[s0] * s_win[2 * n], x[s1] * s_win[2 * n + 1]};
+            }
+        }
+        wave_lds_sync();
+        // ---- step 1: Y[k1][n2] = sum_{n1<25} z[8 n1 + n2] W_25^(n1 k1), then * W_200^(n2 k1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = lane + 64 * i;
+            if (o < kWHalf) {
+                const int k1 = o >> 3, n2 = o & 7;
+                v2f acc = v2f{0.0f, 0.0f};
+                int e = 0;  // (8 * n1 * k1) mod 200
+                for (int n1 = 0; n1 < 25; ++n1) {
+                    acc += cmul(z[8 * n1 + n2], s_tw200[e]);
+                    e += 8 * k1;
+                    if (e >= kWHalf) e -= kWHalf;
+                }
+                y[o] = cmul(acc, s_tw200[n2 * k1]);
+            }
+        }
+        wave_lds_sync();
+        // ---- step 2: Z[k1 + 25 k2] = sum_{n2<8} Y'[k1][n2] W_8^(n2 k2)
+        v2f zk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = lane + 64 * i;
+            zk[i] = v2f{0.0f, 0.0f};
+            if (o < kWHalf) {
+                const int k1 = o % 25, k2 = o / 25;
+                v2f acc = v2f{0.0f, 0.0f};
+#pragma unroll
+                for (int n2 = 0; n2 < 8; ++n2) acc += cmul(y[k1 * 8 + n2], s_tw200[(25 * n2 * k2) % kWHalf]);
+                zk[i] = acc;
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = lane + 64 * i;
+            if (o < kWHalf) z[o] = zk[i];
+        }
+        wave_lds_sync();
+        // ---- real-FFT unpack to bins 0..200 and |X|^2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
+            if (k < kWBins) {
+                const v2f za = z[k % kWHalf];
+                const v2f zb = z[(kWHalf - k) % kWHalf];
+                const v2f e2 = v2f{za.x + zb.x, za.y - zb.y};
+                const v2f o2 = v2f{za.y + zb.y, zb.x - za.x};
+                const v2f xk = 0.5f * (e2 + cmul(o2, s_tw400[k]));
+                p[k] = xk.x * xk.x + xk.y * xk.y;
+            }
+        }
+        wave_lds_sync();
+        // ---- sparse mel, log10
+        {
+            float a0 = 0.0f, a1 = 0.0f;
+            const int nmax = max(rng0.y, rng1.y);
+            for (int j = 0; j < nmax; ++j) {
+                if (j < rng0.y) a0 = fmaf(s_melw[rng0.z + j], p[rng0.x + j], a0);
+                if (j < rng1.y) a1 = fmaf(s_melw[rng1.z + j], p[rng1.x + j], a1);
+            }
+            if (lane < wt.n_mels) {
+                const float l = log10f(fmaxf(a0, 1e-10f));
+                s_tile[lane][f] = l;
+                vmax = fmaxf(vmax, l);
+            }
+            if (lane + 64 < wt.n_mels) {
+                const float l = log10f(fmaxf(a1, 1e-10f));
+                s_tile[lane + 64][f] = l;
+                vmax = fmaxf(vmax, l);
+            }
+        }
+        wave_lds_sync();
+    }
+    vmax = wave_max(vmax);
+    if (lane == 0) s_red[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+        const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        if (m > -INFINITY) atomicMax(&clip_max[clip], float_key(m));
+    }
+    // ---- coalesced store of the [n_mels][tile] block (frames are the minor axis)
+    const int valid = min(kWTile, n_frames - t_tile);
+    float* o = out + static_cast<size_t>(clip) * wt.n_mels * n_frames + t_tile;
+    for (int i = tid; i < wt.n_mels * kWTile; i += 256) {
+        const int m = i >> 6, f = i & 63;
+        if (f < valid) o[static_cast<size_t>(m) * n_frames + f] = s_tile[m][f];
+    }
+}
+
+// pass 2: out = (max(out, clip_max - 8) + 4) / 4
+__global__ __launch_bounds__(256) void k_whisper_finalize(float* __restrict__ out, long long per_clip,
+                                                          const unsigned* __restrict__ clip_max) {
+    const int clip = blockIdx.y;
+    const float floor_v = key_float(clip_max[clip]) - 8.0f;
+    float* o = out + static_cast<size_t>(clip) * per_clip;
+    for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < per_clip;
+         i += static_cast<long long>(gridDim.x) * 256) {
+        const float v = fmaxf(o[i], floor_v);
+        o[i] = (v + 4.0f) / 4.0f;
+    }
+}
+
+}  // namespace serhip

@@ -1,0 +1,641 @@
+// libserhip.so -- C ABI (include/serhip.h) over the gfx950 kernels.
+// Host side: argument validation, per-call segment planning (which kernel, how many
+// frames, where in the scratch), workspace management, launches.  No torch types.
+#include "../../include/serhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels_fast.hpp"
+#include "kernels_generic.hpp"
+#include "kernels_whisper.hpp"
+#include "tables.hpp"
+
+using namespace serhip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(SERHIP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int feature_dim_of(uint32_t flags) {
+    return ((flags & SERHIP_FEAT_MFCC) ? kMfcc : 0) + ((flags & SERHIP_FEAT_CHROMA) ? kChroma : 0) +
+           ((flags & SERHIP_FEAT_MEL) ? kMels : 0) + ((flags & SERHIP_FEAT_CONTRAST) ? 7 : 0);
+}
+
+// host tables of the fast plan (n_fft 2048)
+struct HostTables {
+    std::vector<v2f> twA, twB, twU, win;
+    std::vector<float> mel_dense, mel_w, chroma, dct;
+    std::vector<int4> mel_rng;
+    std::vector<double> edges, mel_f, window;
+    int kmin = 0, kmax = -1;
+};
+
+void build_host_tables(int sr, HostTables& h, bool with_chroma) {
+    h.twA.resize(16 * 64);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * kPi * static_cast<double>((l * k1) % 1024) / 1024.0;
+            h.twA[k1 * 64 + l] = v2f{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
+        }
+    h.twB.resize(16 * 4);
+    for (int j1 = 0; j1 < 16; ++j1)
+        for (int m2 = 0; m2 < 4; ++m2) {
+            const double a = -2.0 * kPi * static_cast<double>((m2 * j1) % 64) / 64.0;
+            h.twB[j1 * 4 + m2] = v2f{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
+        }
+    h.twU.resize(8 * 64);
+    for (int r = 0; r < 8; ++r)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * kPi * static_cast<double>(l + 64 * r) / 2048.0;
+            h.twU[r * 64 + l] = v2f{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
+        }
+    h.window = hann_periodic(kNfft);
+    h.win.resize(16 * 64);
+    for (int n1 = 0; n1 < 16; ++n1)
+        for (int l = 0; l < 64; ++l)
+            h.win[n1 * 64 + l] = v2f{static_cast<float>(h.window[128 * n1 + 2 * l]),
+                                     static_cast<float>(h.window[128 * n1 + 2 * l + 1])};
+    h.mel_dense = mel_filterbank(sr, kNfft, kMels);
+    h.mel_rng.assign(kMels, int4{0, 0, 0, 0});
+    h.mel_w.clear();
+    for (int m = 0; m < kMels; ++m) {
+        int first = -1, last = -1;
+        for (int k = 0; k < kBins; ++k)
+            if (h.mel_dense[static_cast<size_t>(m) * kBins + k] != 0.0f) {
+                if (first < 0) first = k;
+                last = k;
+            }
+        if (first >= 0) {
+            h.mel_rng[m] = int4{first, last - first + 1, static_cast<int>(h.mel_w.size()), 0};
+            for (int k = first; k <= last; ++k) h.mel_w.push_back(h.mel_dense[static_cast<size_t>(m) * kBins + k]);
+        }
+    }
+    h.dct = dct_ortho(kMfcc, kMels);
+    h.edges.resize(kTunings);
+    for (int i = 0; i < kTunings; ++i) h.edges[i] = tuning_edge(i);
+    h.mel_f = mel_edges(kMels, static_cast<double>(sr) / 2);
+    piptrack_bin_range(sr, kNfft, &h.kmin, &h.kmax);
+    if (with_chroma) {
+        h.chroma.assign(static_cast<size_t>(kTunings) * kChroma * kBinStride, 0.0f);
+        for (int i = 0; i < kTunings; ++i)
+            chroma_filterbank(sr, kNfft, h.edges[i], h.chroma.data() + static_cast<size_t>(i) * kChroma * kBinStride,
+                              kBinStride);
+    }
+}
+
+}  // namespace
+
+struct serhip_ctx {
+    int device = 0;
+    void* ws = nullptr;          // device workspace (scratch + descriptors)
+    size_t ws_bytes = 0;
+    void* staging = nullptr;     // pinned host staging for descriptors
+    size_t staging_bytes = 0;
+    hipEvent_t staging_done = nullptr;
+    size_t chunk_frames = 0;     // frames of scratch per chunk (0 = default)
+    void* whisper_blob[2] = {nullptr, nullptr};   // tables for n_mels 80 / 128
+    WhisperTables whisper_tb[2] = {};
+};
+
+struct serhip_plan {
+    serhip_ctx* ctx = nullptr;
+    int sample_rate = 0;
+    uint32_t flags = 0;
+    int dim = 0;
+    void* dev_blob = nullptr;    // one allocation holding every table
+    PlanTables tb{};
+    int peak_cap = 0;
+};
+
+namespace {
+
+int ensure_workspace(serhip_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return SERHIP_OK;
+    if (ctx->ws) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    hipError_t e = hipMalloc(&ctx->ws, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(&ctx->ws, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(SERHIP_E_NOMEM, "workspace hipMalloc of " + std::to_string(bytes) + " bytes failed");
+        }
+        ctx->ws_bytes = bytes;
+    } else {
+        ctx->ws_bytes = want;
+    }
+    return SERHIP_OK;
+}
+
+int ensure_staging(serhip_ctx* ctx, size_t bytes) {
+    if (ctx->staging_done) HIP_TRY(hipEventSynchronize(ctx->staging_done));
+    if (bytes <= ctx->staging_bytes) return SERHIP_OK;
+    if (ctx->staging) HIP_TRY(hipHostFree(ctx->staging));
+    ctx->staging = nullptr;
+    ctx->staging_bytes = 0;
+    const size_t want = align_up(bytes * 2, 4096);
+    HIP_TRY(hipHostMalloc(&ctx->staging, want, hipHostMallocDefault));
+    ctx->staging_bytes = want;
+    return SERHIP_OK;
+}
+
+struct ScratchLayout {
+    size_t mags, mel, peaks, cnt, total;
+};
+ScratchLayout scratch_layout(size_t frames, int peak_cap) {
+    ScratchLayout l{};
+    size_t o = 0;
+    l.mags = o;
+    o = align_up(o + frames * kBinStride * sizeof(float), 256);
+    l.mel = o;
+    o = align_up(o + frames * kMels * sizeof(float), 256);
+    l.peaks = o;
+    o = align_up(o + frames * static_cast<size_t>(peak_cap) * sizeof(v2f), 256);
+    l.cnt = o;
+    o = align_up(o + frames * sizeof(int), 256);
+    l.total = o;
+    return l;
+}
+Scratch scratch_at(char* base, const ScratchLayout& l, int peak_cap) {
+    Scratch s{};
+    s.mags = reinterpret_cast<float*>(base + l.mags);
+    s.mel = reinterpret_cast<float*>(base + l.mel);
+    s.peaks = reinterpret_cast<v2f*>(base + l.peaks);
+    s.peak_cnt = reinterpret_cast<int*>(base + l.cnt);
+    s.peak_cap = peak_cap;
+    return s;
+}
+
+constexpr int kGenericPeakCap = 520;  // > (1 + 2047/2) / 2 local maxima per frame
+
+// constant tables of the Whisper front end (16 kHz, n_fft 400), built once per n_mels
+int ensure_whisper_tables(serhip_ctx* ctx, int n_mels) {
+    const int slot = (n_mels == 80) ? 0 : 1;
+    if (ctx->whisper_blob[slot]) return SERHIP_OK;
+    std::vector<v2f> tw200(kWHalf), tw400(kWBins);
+    for (int m = 0; m < kWHalf; ++m) {
+        const double a = -2.0 * kPi * m / 200.0;
+        tw200[m] = v2f{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
+    }
+    for (int k = 0; k < kWBins; ++k) {
+        const double a = -2.0 * kPi * k / 400.0;
+        tw400[k] = v2f{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
+    }
+    std::vector<float> win(kWNfft);
+    for (int j = 0; j < kWNfft; ++j) win[j] = static_cast<float>(0.5 - 0.5 * std::cos(2.0 * kPi * j / 400.0));
+    const std::vector<float> dense = mel_filterbank(16000, kWNfft, n_mels);
+    std::vector<float> mel_w;
+    std::vector<int4> rng(n_mels, int4{0, 0, 0, 0});
+    for (int m = 0; m < n_mels; ++m) {
+        int first = -1, last = -1;
+        for (int k = 0; k < kWBins; ++k)
+            if (dense[static_cast<size_t>(m) * kWBins + k] != 0.0f) {
+                if (first < 0) first = k;
+                last = k;
+            }
+        if (first >= 0) {
+            rng[m] = int4{first, last - first + 1, static_cast<int>(mel_w.size()), 0};
+            for (int k = first; k <= last; ++k) mel_w.push_back(dense[static_cast<size_t>(m) * kWBins + k]);
+        }
+    }
+    if (static_cast<int>(mel_w.size()) > kWMelWCap) return fail(SERHIP_E_UNSUPPORTED, "whisper mel taps exceed capacity");
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o = align_up(o + bytes, 256);
+        return at;
+    };
+    const size_t o200 = take(tw200.size() * sizeof(v2f)), o400 = take(tw400.size() * sizeof(v2f)),
+                 owin = take(win.size() * sizeof(float)), omw = take(std::max<size_t>(mel_w.size(), 1) * sizeof(float)),
+                 orng = take(rng.size() * sizeof(int4));
+    std::vector<char> blob(o, 0);
+    std::memcpy(blob.data() + o200, tw200.data(), tw200.size() * sizeof(v2f));
+    std::memcpy(blob.data() + o400, tw400.data(), tw400.size() * sizeof(v2f));
+    std::memcpy(blob.data() + owin, win.data(), win.size() * sizeof(float));
+    if (!mel_w.empty()) std::memcpy(blob.data() + omw, mel_w.data(), mel_w.size() * sizeof(float));
+    std::memcpy(blob.data() + orng, rng.data(), rng.size() * sizeof(int4));
+    void* dev = nullptr;
+    if (hipMalloc(&dev, o) != hipSuccess) return fail(SERHIP_E_NOMEM, "whisper table hipMalloc failed");
+    if (hipMemcpy(dev, blob.data(), o, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(dev);
+        return fail(SERHIP_E_HIP, "whisper table upload failed");
+    }
+    char* d = static_cast<char*>(dev);
+    WhisperTables& wt = ctx->whisper_tb[slot];
+    wt.tw200 = reinterpret_cast<const v2f*>(d + o200);
+    wt.tw400 = reinterpret_cast<const v2f*>(d + o400);
+    wt.win = reinterpret_cast<const float*>(d + owin);
+    wt.mel_w = reinterpret_cast<const float*>(d + omw);
+    wt.mel_rng = reinterpret_cast<const int4*>(d + orng);
+    wt.mel_nnz = static_cast<int>(mel_w.size());
+    wt.n_mels = n_mels;
+    ctx->whisper_blob[slot] = dev;
+    return SERHIP_OK;
+}
+
+int whisper_logmel_launch(serhip_ctx* ctx, const float* audio_dev, int32_t n_clips, int64_t n_samples, int32_t n_mels,
+                          float* out_dev, hipStream_t stream) {
+    int rc = ensure_whisper_tables(ctx, n_mels);
+    if (rc != SERHIP_OK) return rc;
+    if (n_clips > 65535) return fail(SERHIP_E_UNSUPPORTED, "serhip_whisper_logmel: more than 65535 clips per call");
+    rc = ensure_workspace(ctx, align_up(static_cast<size_t>(n_clips) * sizeof(unsigned), 256));
+    if (rc != SERHIP_OK) return rc;
+    unsigned* clip_max = reinterpret_cast<unsigned*>(ctx->ws);
+    HIP_TRY(hipMemsetAsync(clip_max, 0, static_cast<size_t>(n_clips) * sizeof(unsigned), stream));
+    const int n_frames = static_cast<int>(n_samples / kWHop);
+    const WhisperTables& wt = ctx->whisper_tb[n_mels == 80 ? 0 : 1];
+    const dim3 grid((n_frames + kWTile - 1) / kWTile, static_cast<unsigned>(n_clips));
+    hipLaunchKernelGGL(k_whisper_frames, grid, dim3(256), 0, stream, audio_dev, static_cast<long long>(n_samples),
+                       n_frames, wt, out_dev, clip_max);
+    const long long per_clip = static_cast<long long>(n_mels) * n_frames;
+    const unsigned gx = static_cast<unsigned>(std::min<long long>((per_clip + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_whisper_finalize, dim3(gx, static_cast<unsigned>(n_clips)), dim3(256), 0, stream, out_dev,
+                       per_clip, clip_max);
+    HIP_TRY(hipGetLastError());
+    return SERHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int serhip_version(void) { return 100; }
+
+const char* serhip_last_error(void) { return g_last_error.c_str(); }
+
+int serhip_create(int device_id, serhip_ctx** out) {
+    if (!out) return fail(SERHIP_E_INVALID, "serhip_create: out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device_id < 0 || device_id >= n_dev)
+        return fail(SERHIP_E_INVALID, "serhip_create: device " + std::to_string(device_id) + " of " +
+                                          std::to_string(n_dev) + " does not exist");
+    HIP_TRY(hipSetDevice(device_id));
+    serhip_ctx* ctx = new serhip_ctx();
+    ctx->device = device_id;
+    if (hipEventCreateWithFlags(&ctx->staging_done, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return fail(SERHIP_E_HIP, "serhip_create: hipEventCreate failed");
+    }
+    if (const char* env = std::getenv("SERHIP_CHUNK_FRAMES")) {
+        const long long v = std::atoll(env);
+        if (v > 0) ctx->chunk_frames = static_cast<size_t>(v);
+    }
+    *out = ctx;
+    return SERHIP_OK;
+}
+
+void serhip_destroy(serhip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    for (void* b : ctx->whisper_blob)
+        if (b) (void)hipFree(b);
+    if (ctx->staging) (void)hipHostFree(ctx->staging);
+    if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
+    delete ctx;
+}
+
+int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, serhip_plan** out) {
+    if (!ctx || !out) return fail(SERHIP_E_INVALID, "serhip_plan_fast: NULL argument");
+    *out = nullptr;
+    if (sample_rate <= 0) return fail(SERHIP_E_INVALID, "serhip_plan_fast: sample_rate must be positive");
+    if (feature_flags & ~15u) return fail(SERHIP_E_INVALID, "serhip_plan_fast: unknown feature flag bits");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HostTables h;
+    const bool with_chroma = (feature_flags & SERHIP_FEAT_CHROMA) != 0;
+    build_host_tables(sample_rate, h, with_chroma);
+    if (static_cast<int>(h.mel_w.size()) > kMelWCap)
+        return fail(SERHIP_E_UNSUPPORTED, "serhip_plan_fast: mel filterbank has too many taps for this sample rate");
+    if (with_chroma && h.kmax >= kBins - 1)
+        return fail(SERHIP_E_UNSUPPORTED,
+                    "serhip_plan_fast: piptrack range reaches the Nyquist bin (sample_rate <= 8000) -- not implemented");
+
+    // one device blob, sub-allocated
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o = align_up(o + bytes, 256);
+        return at;
+    };
+    const size_t o_twA = take(h.twA.size() * sizeof(v2f)), o_twB = take(h.twB.size() * sizeof(v2f)),
+                 o_twU = take(h.twU.size() * sizeof(v2f)), o_win = take(h.win.size() * sizeof(v2f)),
+                 o_melw = take(std::max<size_t>(h.mel_w.size(), 1) * sizeof(float)),
+                 o_rng = take(h.mel_rng.size() * sizeof(int4)),
+                 o_chroma = take(std::max<size_t>(h.chroma.size(), 1) * sizeof(float)),
+                 o_dct = take(h.dct.size() * sizeof(float)), o_edges = take(h.edges.size() * sizeof(double)),
+                 o_melf = take(h.mel_f.size() * sizeof(double));
+    std::vector<char> blob(o, 0);
+    auto put = [&](size_t at, const void* src, size_t bytes) {
+        if (bytes) std::memcpy(blob.data() + at, src, bytes);
+    };
+    put(o_twA, h.twA.data(), h.twA.size() * sizeof(v2f));
+    put(o_twB, h.twB.data(), h.twB.size() * sizeof(v2f));
+    put(o_twU, h.twU.data(), h.twU.size() * sizeof(v2f));
+    put(o_win, h.win.data(), h.win.size() * sizeof(v2f));
+    put(o_melw, h.mel_w.data(), h.mel_w.size() * sizeof(float));
+    put(o_rng, h.mel_rng.data(), h.mel_rng.size() * sizeof(int4));
+    put(o_chroma, h.chroma.data(), h.chroma.size() * sizeof(float));
+    put(o_dct, h.dct.data(), h.dct.size() * sizeof(float));
+    put(o_edges, h.edges.data(), h.edges.size() * sizeof(double));
+    put(o_melf, h.mel_f.data(), h.mel_f.size() * sizeof(double));
+
+    serhip_plan* plan = new serhip_plan();
+    plan->ctx = ctx;
+    plan->sample_rate = sample_rate;
+    plan->flags = feature_flags;
+    plan->dim = feature_dim_of(feature_flags);
+    if (hipMalloc(&plan->dev_blob, o) != hipSuccess) {
+        delete plan;
+        return fail(SERHIP_E_NOMEM, "serhip_plan_fast: hipMalloc of the table blob failed");
+    }
+    if (hipMemcpy(plan->dev_blob, blob.data(), o, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(plan->dev_blob);
+        delete plan;
+        return fail(SERHIP_E_HIP, "serhip_plan_fast: table upload failed");
+    }
+    char* d = static_cast<char*>(plan->dev_blob);
+    PlanTables& tb = plan->tb;
+    tb.twA = reinterpret_cast<const v2f*>(d + o_twA);
+    tb.twB = reinterpret_cast<const v2f*>(d + o_twB);
+    tb.twU = reinterpret_cast<const v2f*>(d + o_twU);
+    tb.win = reinterpret_cast<const v2f*>(d + o_win);
+    tb.mel_w = reinterpret_cast<const float*>(d + o_melw);
+    tb.mel_rng = reinterpret_cast<const int4*>(d + o_rng);
+    tb.chroma = reinterpret_cast<const float*>(d + o_chroma);
+    tb.dct = reinterpret_cast<const float*>(d + o_dct);
+    tb.edges = reinterpret_cast<const double*>(d + o_edges);
+    tb.mel_f = reinterpret_cast<const double*>(d + o_melf);
+    tb.mel_nnz = static_cast<int>(h.mel_w.size());
+    tb.kmin = h.kmin;
+    tb.kmax = h.kmax;
+    tb.sample_rate = sample_rate;
+    tb.flags = feature_flags;
+    plan->peak_cap = std::max(8, (h.kmax - h.kmin + 2) / 2 + 2);
+    *out = plan;
+    return SERHIP_OK;
+}
+
+void serhip_plan_destroy(serhip_plan* plan) {
+    if (!plan) return;
+    (void)hipSetDevice(plan->ctx->device);
+    (void)hipDeviceSynchronize();
+    if (plan->dev_blob) (void)hipFree(plan->dev_blob);
+    delete plan;
+}
+
+int serhip_plan_feature_dim(const serhip_plan* plan) { return plan ? plan->dim : SERHIP_E_INVALID; }
+
+int64_t serhip_frame_count(int64_t n_samples) {
+    if (n_samples < 1) return SERHIP_E_INVALID;
+    const int64_t np = std::max<int64_t>(n_samples, 512);
+    if (np >= kNfft) return 1 + np / kHop;
+    const int64_t n = np, hop = n / 4;
+    return 1 + (np + 2 * (n / 2) - n) / hop;
+}
+
+int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_audio, const int64_t* seg_offset,
+                         const int64_t* seg_len, int64_t n_seg, float* out_dev, float* tuning_dev, void* stream_v) {
+    if (!plan) return fail(SERHIP_E_INVALID, "serhip_fast_features: plan is NULL");
+    if (n_seg < 0) return fail(SERHIP_E_INVALID, "serhip_fast_features: n_seg < 0");
+    if (n_seg == 0) return SERHIP_OK;
+    if (plan->dim == 0) return SERHIP_OK;
+    if (!audio_dev || !seg_offset || !seg_len || !out_dev)
+        return fail(SERHIP_E_INVALID, "serhip_fast_features: NULL buffer");
+    serhip_ctx* ctx = plan->ctx;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // ---- plan the call: classify segments, count frames, cut chunks
+    struct Chunk {
+        int64_t first, count;    // range in the descriptor array
+        int max_frames;
+        bool generic;
+    };
+    std::vector<SegDesc> descs;
+    descs.reserve(static_cast<size_t>(n_seg));
+    std::vector<SegDesc> generic;
+    size_t chunk_cap = ctx->chunk_frames ? ctx->chunk_frames : (static_cast<size_t>(1) << 18);
+    std::vector<Chunk> chunks;
+    Chunk cur{0, 0, 0, false};
+    size_t cur_frames = 0, max_chunk_frames = 0;
+    for (int64_t i = 0; i < n_seg; ++i) {
+        const int64_t off = seg_offset[i], len = seg_len[i];
+        if (len < 1 || off < 0 || off > n_audio - len)
+            return fail(SERHIP_E_INVALID, "serhip_fast_features: segment " + std::to_string(i) + " [" +
+                                              std::to_string(off) + ", +" + std::to_string(len) +
+                                              ") is empty or outside the audio buffer");
+        if (len > 0x7fffffffLL - 4096) return fail(SERHIP_E_UNSUPPORTED, "serhip_fast_features: segment too long");
+        const int64_t np = std::max<int64_t>(len, 512);
+        SegDesc d{};
+        d.offset = off;
+        d.out_row = i;
+        d.len = static_cast<int>(len);
+        if (np >= kNfft) {
+            d.n_fft = kNfft;
+            d.n_stft = d.n_mel = static_cast<int>(1 + np / kHop);
+            const size_t fr = static_cast<size_t>(d.n_stft);
+            if (cur.count > 0 && (cur_frames + fr > chunk_cap || cur.count >= 65535)) {
+                chunks.push_back(cur);
+                max_chunk_frames = std::max(max_chunk_frames, cur_frames);
+                cur = Chunk{static_cast<int64_t>(descs.size()), 0, 0, false};
+                cur_frames = 0;
+            }
+            d.stft_base = d.mel_base = static_cast<int>(cur_frames);
+            cur_frames += fr;
+            cur.count += 1;
+            cur.max_frames = std::max(cur.max_frames, d.n_stft);
+            descs.push_back(d);
+        } else {
+            const int n = static_cast<int>(np);
+            d.n_fft = n;
+            d.n_stft = static_cast<int>(1 + (np + 2 * (n / 2) - n) / (n / 4));
+            d.n_mel = static_cast<int>(1 + (np + 2 * (n / 2) - n) / kHop);
+            generic.push_back(d);
+        }
+    }
+    if (cur.count > 0) {
+        chunks.push_back(cur);
+        max_chunk_frames = std::max(max_chunk_frames, cur_frames);
+    }
+    if (max_chunk_frames > 0x7fffffffull / 2) return fail(SERHIP_E_UNSUPPORTED, "serhip_fast_features: chunk too large");
+    // generic segments: own chunks, own scratch region
+    size_t gen_frames_max = 0, gen_mel_max = 0;
+    {
+        Chunk g{static_cast<int64_t>(descs.size()), 0, 0, true};
+        size_t gs = 0, gm = 0;
+        for (SegDesc& d : generic) {
+            if (g.count >= 65535 || gs + d.n_stft > 65536) {
+                chunks.push_back(g);
+                gen_frames_max = std::max(gen_frames_max, gs);
+                gen_mel_max = std::max(gen_mel_max, gm);
+                g = Chunk{static_cast<int64_t>(descs.size()), 0, 0, true};
+                gs = gm = 0;
+            }
+            d.stft_base = static_cast<int>(gs);
+            d.mel_base = static_cast<int>(gm);
+            gs += d.n_stft;
+            gm += d.n_mel;
+            g.count += 1;
+            g.max_frames = std::max(g.max_frames, d.n_stft + d.n_mel);
+            descs.push_back(d);
+        }
+        if (g.count > 0) {
+            chunks.push_back(g);
+            gen_frames_max = std::max(gen_frames_max, gs);
+            gen_mel_max = std::max(gen_mel_max, gm);
+        }
+    }
+
+    // ---- workspace: [descriptors | fast scratch | generic scratch]
+    const size_t desc_bytes = align_up(descs.size() * sizeof(SegDesc), 256);
+    const ScratchLayout lf = scratch_layout(max_chunk_frames, plan->peak_cap);
+    const ScratchLayout lg = scratch_layout(std::max(gen_frames_max, gen_mel_max), kGenericPeakCap);
+    int rc = ensure_workspace(ctx, desc_bytes + lf.total + lg.total);
+    if (rc != SERHIP_OK) return rc;
+    rc = ensure_staging(ctx, descs.size() * sizeof(SegDesc));
+    if (rc != SERHIP_OK) return rc;
+    std::memcpy(ctx->staging, descs.data(), descs.size() * sizeof(SegDesc));
+    char* ws = static_cast<char*>(ctx->ws);
+    SegDesc* d_descs = reinterpret_cast<SegDesc*>(ws);
+    HIP_TRY(hipMemcpyAsync(d_descs, ctx->staging, descs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(ctx->staging_done, stream));
+    const Scratch sf = scratch_at(ws + desc_bytes, lf, plan->peak_cap);
+    const Scratch sg = scratch_at(ws + desc_bytes + lf.total, lg, kGenericPeakCap);
+
+    // ---- launches
+    for (const Chunk& c : chunks) {
+        const SegDesc* dd = d_descs + c.first;
+        if (!c.generic) {
+            const dim3 grid((c.max_frames + kFramesPerBlock - 1) / kFramesPerBlock, static_cast<unsigned>(c.count));
+            hipLaunchKernelGGL(k_stft_frames, grid, dim3(kWaves * 64), 0, stream, audio_dev, dd, plan->tb, sf);
+            hipLaunchKernelGGL(k_segment_finish, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
+                               plan->tb, sf, out_dev, tuning_dev, plan->dim);
+        } else {
+            const dim3 grid(static_cast<unsigned>(c.max_frames), static_cast<unsigned>(c.count));
+            hipLaunchKernelGGL(k_dft_frames, grid, dim3(256), 0, stream, audio_dev, dd, plan->tb, sg);
+            hipLaunchKernelGGL(k_segment_finish, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
+                               plan->tb, sg, out_dev, tuning_dev, plan->dim);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return SERHIP_OK;
+}
+
+int serhip_pool_windows(serhip_ctx* ctx, const float* emb_dev, int32_t n_frames, int32_t dim, const int32_t* win_lo,
+                        const int32_t* win_hi, int32_t n_win, int mode, double* out_dev, void* stream_v) {
+    if (!ctx) return fail(SERHIP_E_INVALID, "serhip_pool_windows: ctx is NULL");
+    if (n_win < 0 || n_frames < 0 || dim < 0) return fail(SERHIP_E_INVALID, "serhip_pool_windows: negative size");
+    if (mode != 0 && mode != 1) return fail(SERHIP_E_INVALID, "serhip_pool_windows: mode must be 0 or 1");
+    if (n_win == 0 || dim == 0) return SERHIP_OK;
+    if (!emb_dev || !win_lo || !win_hi || !out_dev) return fail(SERHIP_E_INVALID, "serhip_pool_windows: NULL buffer");
+    if (n_win > 65535) return fail(SERHIP_E_UNSUPPORTED, "serhip_pool_windows: more than 65535 windows per call");
+    for (int i = 0; i < n_win; ++i)
+        if (win_lo[i] < 0 || win_hi[i] <= win_lo[i] || win_hi[i] > n_frames)
+            return fail(SERHIP_E_INVALID, "serhip_pool_windows: window " + std::to_string(i) + " is empty or out of range");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(n_win) * sizeof(int32_t);
+    int rc = ensure_workspace(ctx, 2 * align_up(bytes, 256));
+    if (rc != SERHIP_OK) return rc;
+    rc = ensure_staging(ctx, 2 * bytes);
+    if (rc != SERHIP_OK) return rc;
+    std::memcpy(ctx->staging, win_lo, bytes);
+    std::memcpy(static_cast<char*>(ctx->staging) + bytes, win_hi, bytes);
+    int* d_lo = reinterpret_cast<int*>(ctx->ws);
+    int* d_hi = reinterpret_cast<int*>(static_cast<char*>(ctx->ws) + align_up(bytes, 256));
+    HIP_TRY(hipMemcpyAsync(d_lo, ctx->staging, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_hi, static_cast<char*>(ctx->staging) + bytes, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(ctx->staging_done, stream));
+    const dim3 grid((dim + 255) / 256, static_cast<unsigned>(n_win));
+    hipLaunchKernelGGL(k_pool_windows, grid, dim3(256), 0, stream, emb_dev, dim, d_lo, d_hi, n_win, mode, out_dev);
+    HIP_TRY(hipGetLastError());
+    return SERHIP_OK;
+}
+
+int serhip_whisper_logmel(serhip_ctx* ctx, const float* audio_dev, int32_t n_clips, int64_t n_samples, int32_t n_mels,
+                          float* out_dev, void* stream_v) {
+    if (!ctx) return fail(SERHIP_E_INVALID, "serhip_whisper_logmel: ctx is NULL");
+    if (n_clips < 0) return fail(SERHIP_E_INVALID, "serhip_whisper_logmel: n_clips < 0");
+    if (n_clips == 0) return SERHIP_OK;
+    if (!audio_dev || !out_dev) return fail(SERHIP_E_INVALID, "serhip_whisper_logmel: NULL buffer");
+    if (n_mels != 80 && n_mels != 128) return fail(SERHIP_E_INVALID, "serhip_whisper_logmel: n_mels must be 80 or 128");
+    if (n_samples <= 200)
+        return fail(SERHIP_E_INVALID, "serhip_whisper_logmel: n_samples must be > 200 (reflect padding)");
+    if (n_samples / 160 > 0x7fffffffLL / 256) return fail(SERHIP_E_UNSUPPORTED, "serhip_whisper_logmel: clip too long");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return whisper_logmel_launch(ctx, audio_dev, n_clips, n_samples, n_mels, out_dev, stream);
+}
+
+int64_t serhip_host_table(int sample_rate, int which, int arg, float* out, int64_t out_cap) {
+    if (sample_rate <= 0) return fail(SERHIP_E_INVALID, "serhip_host_table: sample_rate must be positive");
+    std::vector<float> v;
+    switch (which) {
+        case 0: {
+            const std::vector<double> w = hann_periodic(kNfft);
+            v.assign(w.begin(), w.end());
+            break;
+        }
+        case 1:
+            v = mel_filterbank(sample_rate, kNfft, kMels);
+            break;
+        case 2: {
+            if (arg < 0 || arg >= kTunings) return fail(SERHIP_E_INVALID, "serhip_host_table: tuning index out of range");
+            std::vector<float> padded(static_cast<size_t>(kChroma) * kBinStride, 0.0f);
+            chroma_filterbank(sample_rate, kNfft, tuning_edge(arg), padded.data(), kBinStride);
+            v.resize(static_cast<size_t>(kChroma) * kBins);
+            for (int c = 0; c < kChroma; ++c)
+                std::copy(padded.begin() + static_cast<size_t>(c) * kBinStride,
+                          padded.begin() + static_cast<size_t>(c) * kBinStride + kBins, v.begin() + static_cast<size_t>(c) * kBins);
+            break;
+        }
+        case 3:
+            v = dct_ortho(kMfcc, kMels);
+            break;
+        case 4: {
+            int lo, hi;
+            piptrack_bin_range(sample_rate, kNfft, &lo, &hi);
+            v = {static_cast<float>(lo), static_cast<float>(hi)};
+            break;
+        }
+        default:
+            return fail(SERHIP_E_INVALID, "serhip_host_table: unknown table id");
+    }
+    const int64_t n = static_cast<int64_t>(v.size());
+    if (!out) return n;
+    if (out_cap < n) return fail(SERHIP_E_INVALID, "serhip_host_table: output buffer too small");
+    std::memcpy(out, v.data(), v.size() * sizeof(float));
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+"""Signal-level feature extraction with the reference's call signature.
+
+``extract_feature_from_signal(audio, sample_rate, *, feature_flags=None)`` mirrors
+``ser/_internal/utils/dsp.py:67-151``: same validation order and messages, same
+output order ``[mfcc40 | chroma12 | mel128 | contrast7]`` and float64 result;
+the arithmetic runs in the gfx950 kernels behind ``serhip_fast_features``.
+"""
+
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+from numpy.typing import NDArray
+
+from .engine import get_engine
+from .types import FAST_PATH_FLAGS, FeatureFlags, FeatureVector
+
+logger = logging.getLogger(__name__)
+
+#: librosa raises ParameterError when 200*2**k octave band edges reach Nyquist
+CONTRAST_MIN_SAMPLE_RATE = 12800
+
+
+class ParameterError(Exception):
+    """Counterpart of ``librosa.util.exceptions.ParameterError`` raised through dsp.py:129."""
+
+
+def validate_signal(audio: NDArray[np.float32], sample_rate: int) -> NDArray[np.float32]:
+    """Input checks of dsp.py:85-95, in the reference's order; returns a float32 view/copy."""
+    if sample_rate <= 0:
+        raise ValueError("Sample rate must be a positive integer.")
+    if audio.ndim != 1:
+        raise ValueError("Audio must be mono (1D array).")
+    if audio.size == 0:
+        raise ValueError("Audio contains no samples.")
+    prepared = np.asarray(audio, dtype=np.float32)
+    if not bool(np.all(np.isfinite(prepared))):
+        raise ValueError("Audio buffer is not finite everywhere.")
+    return prepared
+
+
+def check_flags_for_rate(flags: FeatureFlags, sample_rate: int) -> None:
+    """Errors the reference's librosa calls raise for a (flags, sample_rate) pair."""
+    if flags.contrast and sample_rate <= CONTRAST_MIN_SAMPLE_RATE:
+        raise ParameterError("Frequency band exceeds Nyquist. Reduce either fmin or n_bands.")
+
+
+def extract_feature_from_signal(
+    audio: NDArray[np.float32],
+    sample_rate: int,
+    *,
+    feature_flags: FeatureFlags | None = None,
+) -> FeatureVector:
+    """Extract the configured features from an in-memory mono signal (float64 vector).
+
+    ``feature_flags=None`` selects the accelerated 187-dim configuration
+    (``FeatureFlags(tonnetz=False)``); the reference's own default additionally
+    enables tonnetz, which this package does not implement.
+    """
+    flags = feature_flags if feature_flags is not None else FAST_PATH_FLAGS
+    prepared = validate_signal(audio, sample_rate)
+    try:
+        if flags.tonnetz:
+            raise NotImplementedError(
+                "tonnetz features are outside the accelerated path; use FeatureFlags(tonnetz=False)"
+            )
+        if flags.width() == 0:
+            return np.empty(0, dtype=np.float64)
+        check_flags_for_rate(flags, sample_rate)
+        engine = get_engine()
+        out = engine.features(prepared, [0], [prepared.size], sample_rate, flags)
+        vector = out[0].cpu().numpy()
+    except Exception as err:
+        logger.warning("Error extracting features from signal: %s", err)
+        raise
+    return vector.astype(np.float64, copy=False)

@@ -1,0 +1,185 @@
+"""Batched GPU feature engine: the host side of ``serhip_fast_features``.
+
+One :class:`FeatureEngine` per (process, GPU).  Audio lives in HBM as a torch
+tensor (torch is used for device memory and streams only); segments are
+(offset, length) descriptors into it, so overlapping sliding windows need no
+copies.  Every call goes through the C ABI; there is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+from . import _native
+from .types import FeatureFlags
+
+_engines: dict[tuple[int, int], "FeatureEngine"] = {}
+_engines_lock = threading.Lock()
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "ser_amd needs an AMD GPU (torch.cuda.is_available() is False) -- there is no CPU fallback; "
+            "the CPU restatement under oracle/ is test infrastructure only"
+        )
+    return torch
+
+
+def get_engine(device_index: int | None = None) -> "FeatureEngine":
+    """Process-local engine for ``device_index`` (default: torch's current device).
+
+    Created lazily and keyed by PID so a forked ``multiprocessing`` worker builds
+    its own HIP context instead of reusing the parent's.
+    """
+    torch = _torch()
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    key = (os.getpid(), int(device_index))
+    with _engines_lock:
+        eng = _engines.get(key)
+        if eng is None:
+            eng = FeatureEngine(int(device_index))
+            _engines[key] = eng
+        return eng
+
+
+def _as_i64(values) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(values, dtype=np.int64))
+
+
+class FeatureEngine:
+    """Owns one ``serhip_ctx`` and its plans; serialises calls with a lock."""
+
+    def __init__(self, device_index: int = 0) -> None:
+        self._torch = _torch()
+        self.device_index = int(device_index)
+        self.device = self._torch.device("cuda", self.device_index)
+        with self._torch.cuda.device(self.device):
+            self._ctx = _native.Context(self.device_index)
+        self._lib = _native.load_library()
+        self._lock = threading.Lock()
+
+    # ------------------------------------------------------------------ buffers
+    def to_device(self, audio) -> "object":
+        """float32 contiguous 1-D (or 2-D for whisper) tensor on this engine's GPU."""
+        torch = self._torch
+        if isinstance(audio, torch.Tensor):
+            t = audio.to(device=self.device, dtype=torch.float32)
+        else:
+            arr = np.ascontiguousarray(np.asarray(audio, dtype=np.float32))
+            t = torch.from_numpy(arr).to(self.device)
+        return t.contiguous()
+
+    def _stream(self) -> c_void_p:
+        return c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ hot path
+    def features(self, audio, seg_offset, seg_len, sample_rate: int, flags: FeatureFlags, *,
+                 return_tuning: bool = False):
+        """Feature matrix ``[n_seg, D]`` (float32, on device) for segments of ``audio``.
+
+        ``audio`` is a 1-D float32 numpy array or torch tensor (moved to the GPU if
+        needed); ``seg_offset`` / ``seg_len`` are host integer sequences.
+        """
+        if flags.tonnetz:
+            raise NotImplementedError(
+                "tonnetz features (HPSS + constant-Q chroma) are outside the accelerated path; "
+                "use FeatureFlags(tonnetz=False)"
+            )
+        torch = self._torch
+        audio_dev = self.to_device(audio)
+        if audio_dev.dim() != 1:
+            raise ValueError("audio must be a 1-D sample buffer")
+        off = _as_i64(seg_offset)
+        length = _as_i64(seg_len)
+        if off.shape != length.shape or off.ndim != 1:
+            raise ValueError("seg_offset and seg_len must be 1-D and the same length")
+        n_seg = int(off.shape[0])
+        dim = flags.width()
+        with self._torch.cuda.device(self.device), self._lock:
+            plan = self._ctx.plan(int(sample_rate), flags.native_bits())
+            out = torch.empty((n_seg, dim), dtype=torch.float32, device=self.device)
+            tuning = torch.empty((n_seg,), dtype=torch.float32, device=self.device) if return_tuning else None
+            if n_seg and dim:
+                _native.check(
+                    self._lib.serhip_fast_features(
+                        plan.handle,
+                        c_void_p(audio_dev.data_ptr()),
+                        int(audio_dev.numel()),
+                        off.ctypes.data_as(POINTER(c_int64)),
+                        length.ctypes.data_as(POINTER(c_int64)),
+                        n_seg,
+                        c_void_p(out.data_ptr()),
+                        c_void_p(tuning.data_ptr()) if tuning is not None else None,
+                        self._stream(),
+                    )
+                )
+            # the kernels read audio_dev asynchronously: keep it alive until they are enqueued
+            # on the same stream the caller will synchronise (torch's caching allocator is
+            # stream-ordered, so releasing the tensor after this point is safe)
+        if return_tuning:
+            return out, tuning
+        return out
+
+    # ------------------------------------------------------------------ pooling
+    def pool_windows(self, embeddings, win_lo, win_hi, *, mode: int):
+        """Pool rows ``[lo, hi)`` of ``embeddings`` per window; returns a float64 device tensor."""
+        torch = self._torch
+        emb = self.to_device(embeddings)
+        if emb.dim() != 2:
+            raise ValueError("embeddings must be 2-D (frames, features)")
+        lo = np.ascontiguousarray(np.asarray(win_lo, dtype=np.int32))
+        hi = np.ascontiguousarray(np.asarray(win_hi, dtype=np.int32))
+        n_win, (n_frames, dim) = int(lo.shape[0]), emb.shape
+        width = dim * 2 if mode == 0 else dim
+        with self._torch.cuda.device(self.device), self._lock:
+            out = torch.empty((n_win, width), dtype=torch.float64, device=self.device)
+            for start in range(0, n_win, 65535):
+                stop = min(n_win, start + 65535)
+                _native.check(
+                    self._lib.serhip_pool_windows(
+                        self._ctx.handle,
+                        c_void_p(emb.data_ptr()),
+                        int(n_frames),
+                        int(dim),
+                        lo[start:stop].ctypes.data_as(POINTER(c_int32)),
+                        hi[start:stop].ctypes.data_as(POINTER(c_int32)),
+                        stop - start,
+                        int(mode),
+                        c_void_p(out[start:stop].data_ptr()),
+                        self._stream(),
+                    )
+                )
+        return out
+
+    # ------------------------------------------------------------------ whisper
+    def whisper_logmel(self, audio, n_mels: int = 80):
+        """``[n_clips, n_mels, n_samples // 160]`` float32 device tensor (clips are rows of ``audio``)."""
+        torch = self._torch
+        a = self.to_device(audio)
+        if a.dim() == 1:
+            a = a.unsqueeze(0)
+        if a.dim() != 2:
+            raise ValueError("audio must be [n_samples] or [n_clips, n_samples]")
+        n_clips, n_samples = int(a.shape[0]), int(a.shape[1])
+        n_frames = n_samples // 160
+        with self._torch.cuda.device(self.device), self._lock:
+            out = torch.empty((n_clips, int(n_mels), n_frames), dtype=torch.float32, device=self.device)
+            _native.check(
+                self._lib.serhip_whisper_logmel(
+                    self._ctx.handle, c_void_p(a.data_ptr()), n_clips, n_samples, int(n_mels),
+                    c_void_p(out.data_ptr()), self._stream(),
+                )
+            )
+        return out
+
+    def close(self) -> None:
+        self._ctx.close()

@@ -1,0 +1,162 @@
+"""``HandcraftedBackend`` -- the fast profile's feature backend, GPU edition.
+
+Interface of ``ser/_internal/repr/handcrafted.py:22-137`` (constructor keywords,
+``backend_id``, ``feature_dim``, ``prepare_runtime``, ``encode_sequence``, ``pool``,
+``extract_vector``).  Where the reference loops over windows in Python and calls the
+DSP function once per window, this backend describes all windows of a recording
+as (offset, length) pairs and featurises them in ONE batched GPU call; the
+batch entry points ``extract_vectors`` / ``encode_sequences`` do the same
+across many recordings (the dataset featurisation loop of
+``ser/_internal/data/data_loader.py:335-535``).
+"""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import numpy as np
+from numpy.typing import NDArray
+
+from . import dsp
+from .engine import get_engine
+from .types import (
+    FAST_PATH_FLAGS,
+    EncodedSequence,
+    FeatureFlags,
+    FeatureMatrix,
+    FeatureVector,
+    PoolingWindow,
+    overlap_frame_range,
+)
+
+
+def sliding_window_bounds(n_samples: int, sample_rate: int, size_seconds, stride_seconds):
+    """Window sample ranges of ``encode_sequence`` (handcrafted.py:78-97) as two int64 arrays."""
+    frame_length = max(1, int(round(size_seconds * sample_rate)))
+    frame_step = max(1, int(round(stride_seconds * sample_rate)))
+    starts = np.arange(0, n_samples, frame_step, dtype=np.int64)
+    ends = np.minimum(starts + frame_length, n_samples)
+    return starts, ends
+
+
+class HandcraftedBackend:
+    """Handcrafted (MFCC / chroma / mel / contrast) backend running on gfx950."""
+
+    def __init__(
+        self,
+        *,
+        frame_size_seconds: int = 3,
+        frame_stride_seconds: int = 1,
+        feature_flags: FeatureFlags | None = None,
+    ) -> None:
+        if frame_size_seconds <= 0:
+            raise ValueError("frame_size_seconds must be greater than zero.")
+        if frame_stride_seconds <= 0:
+            raise ValueError("frame_stride_seconds must be greater than zero.")
+        self._frame_size_seconds = frame_size_seconds
+        self._frame_stride_seconds = frame_stride_seconds
+        self._feature_flags = feature_flags if feature_flags is not None else FAST_PATH_FLAGS
+
+    @property
+    def backend_id(self) -> str:
+        return "handcrafted"
+
+    @property
+    def feature_dim(self) -> int:
+        return self._feature_flags.width()
+
+    @property
+    def feature_flags(self) -> FeatureFlags:
+        return self._feature_flags
+
+    def prepare_runtime(self) -> None:
+        """Warm-up hook: creates the HIP context and uploads nothing else (plans are per sample rate)."""
+        get_engine()
+
+    # ------------------------------------------------------------------ single recording
+    def encode_sequence(self, audio: NDArray[np.float32], sample_rate: int) -> EncodedSequence:
+        """Frame-level features of one recording: all sliding windows in one GPU batch."""
+        if sample_rate <= 0:
+            raise ValueError("sample_rate must be a positive integer.")
+        if audio.ndim != 1:
+            raise ValueError("audio must be mono (1D array).")
+        if audio.size == 0:
+            raise ValueError("audio must contain at least one sample.")
+        return self.encode_sequences([audio], sample_rate)[0]
+
+    def extract_vector(self, audio: NDArray[np.float32], sample_rate: int) -> FeatureVector:
+        """One feature vector for the whole signal (training path)."""
+        return np.asarray(
+            dsp.extract_feature_from_signal(audio, sample_rate, feature_flags=self._feature_flags),
+            dtype=np.float64,
+        )
+
+    def pool(self, encoded: EncodedSequence, windows: Sequence[PoolingWindow]) -> FeatureMatrix:
+        """Mean-pools encoded frames for each window (float32 accumulation, float64 result)."""
+        dim = int(encoded.embeddings.shape[1])
+        if not windows:
+            return np.empty((0, dim), dtype=np.float64)
+        ranges = [overlap_frame_range(encoded, w) for w in windows]
+        lo = [r[0] for r in ranges]
+        hi = [r[1] for r in ranges]
+        out = get_engine().pool_windows(np.asarray(encoded.embeddings, dtype=np.float32), lo, hi, mode=1)
+        return out.cpu().numpy()
+
+    # ------------------------------------------------------------------ batches
+    def extract_vectors(self, audios: Sequence[NDArray[np.float32]], sample_rate: int) -> FeatureMatrix:
+        """``[len(audios), D]`` float64: one vector per whole clip, one GPU batch for all clips."""
+        prepared = [dsp.validate_signal(a, sample_rate) for a in audios]
+        if self._feature_flags.width() == 0 or not prepared:
+            return np.empty((len(prepared), self._feature_flags.width()), dtype=np.float64)
+        dsp.check_flags_for_rate(self._feature_flags, sample_rate)
+        lengths = np.asarray([a.size for a in prepared], dtype=np.int64)
+        offsets = np.concatenate(([0], np.cumsum(lengths)[:-1])).astype(np.int64)
+        packed = np.concatenate(prepared)
+        out = get_engine().features(packed, offsets, lengths, sample_rate, self._feature_flags)
+        return out.cpu().numpy().astype(np.float64)
+
+    def encode_sequences(self, audios: Sequence[NDArray[np.float32]], sample_rate: int) -> list[EncodedSequence]:
+        """Sliding-window features of many recordings in one GPU batch."""
+        if sample_rate <= 0:
+            raise ValueError("sample_rate must be a positive integer.")
+        prepared, bounds = [], []
+        for audio in audios:
+            if audio.ndim != 1:
+                raise ValueError("audio must be mono (1D array).")
+            if audio.size == 0:
+                raise ValueError("audio must contain at least one sample.")
+            a = dsp.validate_signal(audio, sample_rate)
+            prepared.append(a)
+            bounds.append(sliding_window_bounds(a.size, sample_rate, self._frame_size_seconds,
+                                                self._frame_stride_seconds))
+        if not prepared:
+            return []
+        if self._feature_flags.tonnetz:
+            raise NotImplementedError(
+                "tonnetz features are outside the accelerated path; use FeatureFlags(tonnetz=False)"
+            )
+        dsp.check_flags_for_rate(self._feature_flags, sample_rate)
+        base = np.concatenate(([0], np.cumsum([a.size for a in prepared])[:-1])).astype(np.int64)
+        offsets = np.concatenate([b + s for b, (s, _) in zip(base, bounds)])
+        lengths = np.concatenate([e - s for s, e in bounds])
+        dim = self._feature_flags.width()
+        if dim:
+            packed = prepared[0] if len(prepared) == 1 else np.concatenate(prepared)
+            emb = get_engine().features(packed, offsets, lengths, sample_rate, self._feature_flags).cpu().numpy()
+        else:
+            emb = np.empty((offsets.size, 0), dtype=np.float32)
+        result, row = [], 0
+        for starts, ends in bounds:
+            n = starts.size
+            if n == 0:
+                raise ValueError("Could not extract handcrafted features from provided audio.")
+            result.append(
+                EncodedSequence(
+                    embeddings=np.ascontiguousarray(emb[row : row + n], dtype=np.float32),
+                    frame_start_seconds=starts.astype(np.float64) / float(sample_rate),
+                    frame_end_seconds=ends.astype(np.float64) / float(sample_rate),
+                    backend_id=self.backend_id,
+                )
+            )
+            row += n
+        return result

@@ -1,0 +1,172 @@
+"""Boundary data types of the fast feature path.
+
+Same names, fields, validation and error strings as the reference's
+``FeatureFlags`` / ``AudioReadConfig`` (ser/_internal/config/schema.py:219-248),
+``PoolingWindow`` / ``EncodedSequence`` / ``FeatureBackend`` protocols
+(ser/_internal/repr/backend.py:19-155) and ``FeatureFrame``
+(ser/_internal/features/feature_extractor.py:26-32), so callers can swap the
+package in.  Plain picklable dataclasses: no GPU state lives here.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+from dataclasses import dataclass
+from typing import Protocol, runtime_checkable
+
+import numpy as np
+from numpy.typing import NDArray
+
+EmbeddingMatrix = NDArray[np.float32]
+TimeVector = NDArray[np.float64]
+FeatureMatrix = NDArray[np.float64]
+FeatureVector = NDArray[np.float64]
+
+#: width of each feature block, in output order (dsp.py:106-151)
+BLOCK_WIDTHS = (("mfcc", 40), ("chroma", 12), ("mel", 128), ("contrast", 7), ("tonnetz", 6))
+
+
+@dataclass(frozen=True)
+class FeatureFlags:
+    """Feature extraction toggles (reference default: all on, 193 dims).
+
+    ``tonnetz`` (HPSS + constant-Q chroma, 6 dims) is outside the accelerated
+    path: enabling it makes extraction raise ``NotImplementedError``.
+    """
+
+    mfcc: bool = True
+    chroma: bool = True
+    mel: bool = True
+    contrast: bool = True
+    tonnetz: bool = True
+
+    def width(self) -> int:
+        return sum(w for name, w in BLOCK_WIDTHS if getattr(self, name))
+
+    def native_bits(self) -> int:
+        return (1 if self.mfcc else 0) | (2 if self.chroma else 0) | (4 if self.mel else 0) | (8 if self.contrast else 0)
+
+
+#: the 187-dim configuration this package accelerates
+FAST_PATH_FLAGS = FeatureFlags(tonnetz=False)
+
+
+@dataclass(frozen=True)
+class AudioReadConfig:
+    """Retry behaviour for audio loading."""
+
+    max_retries: int = 3
+    retry_delay_seconds: float = 1.0
+
+
+@dataclass(frozen=True)
+class PoolingWindow:
+    """Temporal window used when pooling encoded frame features."""
+
+    start_seconds: float
+    end_seconds: float
+
+    def __post_init__(self) -> None:
+        lo, hi = self.start_seconds, self.end_seconds
+        if not (np.isfinite(lo) and np.isfinite(hi)):
+            raise ValueError("PoolingWindow bounds must be finite numbers.")
+        if lo < 0.0:
+            raise ValueError("PoolingWindow start_seconds must be non-negative.")
+        if hi <= lo:
+            raise ValueError("PoolingWindow end_seconds must be greater than start_seconds.")
+
+
+@dataclass(frozen=True)
+class EncodedSequence:
+    """Frame-level encoded representation with explicit temporal boundaries."""
+
+    embeddings: EmbeddingMatrix
+    frame_start_seconds: TimeVector
+    frame_end_seconds: TimeVector
+    backend_id: str
+
+    def __post_init__(self) -> None:
+        emb, t0, t1 = self.embeddings, self.frame_start_seconds, self.frame_end_seconds
+        if not self.backend_id:
+            raise ValueError("EncodedSequence backend_id must be a non-empty string.")
+        if emb.ndim != 2:
+            raise ValueError("EncodedSequence embeddings must be 2D (frames, features).")
+        if t0.ndim != 1 or t1.ndim != 1:
+            raise ValueError("Frame timestamp arrays must be 1D.")
+        n_frames = int(emb.shape[0])
+        if n_frames <= 0:
+            raise ValueError("EncodedSequence must contain at least one frame.")
+        for label, arr in (("frame_start_seconds", t0), ("frame_end_seconds", t1)):
+            if arr.size != n_frames:
+                raise ValueError(f"{label} length must match embeddings frame count.")
+        for label, arr in (("embeddings", emb), ("frame_start_seconds", t0), ("frame_end_seconds", t1)):
+            if not np.all(np.isfinite(arr)):
+                raise ValueError(f"EncodedSequence {label} contain non-finite values.")
+        for label, arr in (("frame_start_seconds", t0), ("frame_end_seconds", t1)):
+            if np.any(np.diff(arr) < 0.0):
+                raise ValueError(f"{label} must be non-decreasing.")
+        if np.any(t1 <= t0):
+            raise ValueError("Each frame must satisfy end_seconds > start_seconds.")
+
+
+@dataclass(frozen=True)
+class FeatureFrame:
+    """A frame-level feature vector with explicit temporal boundaries."""
+
+    start_seconds: float
+    end_seconds: float
+    features: FeatureVector
+
+
+def overlap_frame_range(encoded: EncodedSequence, window: PoolingWindow) -> tuple[int, int]:
+    """Half-open frame range ``[lo, hi)`` that overlaps ``window``.
+
+    Frame times are non-decreasing (``EncodedSequence`` enforces it), so the
+    frames with ``end > window.start and start < window.end`` are contiguous;
+    the range is what the GPU pooling kernel consumes.  Raises exactly like
+    ``overlap_frame_mask`` (repr/backend.py:94-110).
+    """
+    t0, t1 = encoded.frame_start_seconds, encoded.frame_end_seconds
+    first, last = float(t0[0]), float(t1[-1])
+    if window.start_seconds < first or window.end_seconds > last:
+        raise ValueError(
+            "Pooling window is outside encoded sequence range: "
+            f"[{window.start_seconds}, {window.end_seconds}] vs [{first}, {last}]"
+        )
+    lo = int(np.searchsorted(t1, window.start_seconds, side="right"))   # first frame with end > start
+    hi = int(np.searchsorted(t0, window.end_seconds, side="left"))      # first frame with start >= end
+    if hi <= lo:
+        raise ValueError(
+            f"Pooling window does not overlap any encoded frames: [{window.start_seconds}, {window.end_seconds}]"
+        )
+    return lo, hi
+
+
+def overlap_frame_mask(encoded: EncodedSequence, window: PoolingWindow) -> NDArray[np.bool_]:
+    """Boolean mask form of :func:`overlap_frame_range` (reference signature)."""
+    lo, hi = overlap_frame_range(encoded, window)
+    mask = np.zeros(encoded.frame_start_seconds.shape[0], dtype=bool)
+    mask[lo:hi] = True
+    return mask
+
+
+@runtime_checkable
+class FeatureBackend(Protocol):
+    """Backend protocol for sequence encoding and temporal pooling."""
+
+    @property
+    def backend_id(self) -> str: ...
+
+    @property
+    def feature_dim(self) -> int: ...
+
+    def encode_sequence(self, audio: NDArray[np.float32], sample_rate: int) -> EncodedSequence: ...
+
+    def pool(self, encoded: EncodedSequence, windows: Sequence[PoolingWindow]) -> FeatureMatrix: ...
+
+
+@runtime_checkable
+class VectorFeatureBackend(FeatureBackend, Protocol):
+    """Optional convenience protocol for direct vector extraction."""
+
+    def extract_vector(self, audio: NDArray[np.float32], sample_rate: int) -> FeatureVector: ...
