@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds featurized per second on N MI355X (BASELINE.json).
+
+Workload (config 3 of BASELINE.json): 100 000 synthetic 3-second clips at 16 kHz, sharded
+by utterance, 12 500 clips per GPU (weak scaling: --gpus 8 is exactly config 3), 187-dim
+fast-profile features per clip, then one RCCL all-gather of the feature matrix.  A "step"
+is one pass of the hot path over the rank's batch (inputs already resident in HBM) plus,
+for N > 1, the gather.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (k_stft_frames):
+algorithmic bytes (4*N + 4*D per segment) over its HIP-event duration.
+``cpu_baseline`` is the CPU restatement of the reference (oracle/, numpy+scipy) timed on
+this host's cores on a bounded sample of the same workload (N=1, rank 0 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+SAMPLE_RATE = 16000
+CLIP_SECONDS = 3
+CLIP_SAMPLES = SAMPLE_RATE * CLIP_SECONDS
+FEATURE_DIM = 187
+CLIPS_PER_GPU = 12500
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+ALGO_BYTES_PER_CLIP = 4 * CLIP_SAMPLES + 4 * FEATURE_DIM   # 192 748 B
+
+
+def _cpu_worker(seed: int) -> int:
+    import numpy as np
+
+    from oracle import ser_fast_path as ofp
+    from ser_amd.synth import harmonic_clip
+
+    clip = harmonic_clip(np.random.default_rng(seed), CLIP_SAMPLES, SAMPLE_RATE)
+    ofp.extract_feature_from_signal(clip, SAMPLE_RATE, flags=ofp.Flags())
+    return 1
+
+
+def cpu_baseline(n_clips: int, workers: int) -> dict:
+    """Time the oracle (reference-faithful call structure) on `workers` host processes.
+
+    Runs BEFORE this process touches the GPU: the pool forks plain numpy workers.
+    """
+    import multiprocessing as mp
+
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    ctx = mp.get_context("fork")
+    with ctx.Pool(workers) as pool:
+        pool.map(_cpu_worker, range(workers))            # warm-up: imports, filterbank code paths
+        t0 = time.perf_counter()
+        chunk = max(1, n_clips // (4 * workers))         # reference chunking, data_loader.py:374-379
+        done = sum(pool.imap_unordered(_cpu_worker, range(1000, 1000 + n_clips), chunksize=chunk))
+        dt = time.perf_counter() - t0
+    return {
+        "value": done * CLIP_SECONDS / dt,
+        "unit": "audio-seconds/s",
+        "cores": workers,
+        "kind": "port",
+        "sample": f"{done} of the config-3 clips (3 s @16 kHz), numpy/scipy restatement of the reference "
+                  f"(oracle/), multiprocessing.Pool({workers}) like data_loader.py:374-379, {dt:.1f} s wall",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clips-per-gpu", type=int, default=CLIPS_PER_GPU)
+    ap.add_argument("--cpu-clips", type=int, default=800, help="clips in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    cpu = None
+    if world == 1 and args.cpu_clips > 0:
+        workers = max(1, min(args.cpu_workers, os.cpu_count() or 1, 16))
+        cpu = cpu_baseline(args.cpu_clips, workers)
+
+    import torch
+    import torch.distributed as dist
+
+    from ser_amd import FeatureFlags
+    from ser_amd.distributed import all_gather_rows
+    from ser_amd.engine import get_engine
+    from ser_amd.synth import harmonic_clips_torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n_local = int(args.clips_per_gpu)
+    n_total = n_local * world
+    flags = FeatureFlags(tonnetz=False)
+    engine = get_engine(local_rank)
+    # synthetic shard, generated on the device from a per-rank seed (config 3: seed 1234)
+    audio = harmonic_clips_torch(1234 + rank, n_local, CLIP_SAMPLES, device).reshape(-1)
+    offsets = [i * CLIP_SAMPLES for i in range(n_local)]
+    lengths = [CLIP_SAMPLES] * n_local
+    torch.cuda.synchronize()
+
+    def step():
+        feats = engine.features(audio, offsets, lengths, SAMPLE_RATE, flags)
+        return all_gather_rows(feats, n_total)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    engine._ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    engine._ctx.profile_enable(False)
+    k1_ms, k1_n = engine._ctx.profile_read(0)
+    k2_ms, k2_n = engine._ctx.profile_read(1)
+    assert tuple(out.shape) == (n_total, FEATURE_DIM)
+    assert bool(torch.isfinite(out).all())
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        audio_seconds = n_total * CLIP_SECONDS * args.steps
+        value = audio_seconds / elapsed
+        # dominant kernel: algorithmic bytes of the rank's batch per step / its event time per step
+        k1_s_per_step = (k1_ms / 1e3) / max(1, args.steps)
+        achieved = n_local * ALGO_BYTES_PER_CLIP / k1_s_per_step / 1e9 if k1_s_per_step > 0 else 0.0
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get("k_stft_frames_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "audio-seconds featurized/sec (whole node)",
+            "value": value,
+            "unit": "audio-seconds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "config 3: 100k x 3 s clips @16 kHz sharded by utterance, 12 500 clips per GPU, "
+                            "187-dim fast-profile features (mfcc40|chroma12|mel128|contrast7) + all-gather",
+                "clips_per_gpu": n_local,
+                "clip_samples": CLIP_SAMPLES,
+                "feature_dim": FEATURE_DIM,
+                "parallelism": f"dp{world} by utterance",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_stft_frames",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "launches_per_step": k1_n / max(1, args.steps),
+                "avg_launch_ms": k1_ms / max(1, k1_n),
+                "finish_kernel_ms_per_step": k2_ms / max(1, args.steps),
+                "whole_path_frac": (value / world) * (ALGO_BYTES_PER_CLIP / CLIP_SECONDS) / 1e9 / HBM_PEAK_GBS,
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,19 @@ int serhip_pool_windows(serhip_ctx* ctx, const float* emb_dev, int32_t n_frames,
 int serhip_whisper_logmel(serhip_ctx* ctx, const float* audio_dev, int32_t n_clips,
                           int64_t n_samples, int32_t n_mels, float* out_dev, void* stream);
 
+/* Per-kernel timing with HIP events recorded on the stream each kernel is launched on.
+ * No reference counterpart (the reference's only timer is the phase stopwatch of
+ * ser/_internal/runtime/phase_timing.py:29-78 around whole inferences); bench.py uses
+ * it for the roofline line.  While enabled, every launch made by
+ * serhip_fast_features is bracketed by an event pair; serhip_profile_read waits
+ * for the recorded launches of one kind, returns their summed duration and
+ * count, and forgets them. */
+#define SERHIP_KERNEL_STFT_FRAMES 0     /* k_stft_frames   (framing+FFT+mel+peaks)  */
+#define SERHIP_KERNEL_SEGMENT_FINISH 1  /* k_segment_finish (MFCC, tuning, chroma)   */
+#define SERHIP_KERNEL_DFT_FRAMES 2      /* k_dft_frames    (segments < 2048 samples) */
+int serhip_profile_enable(serhip_ctx* ctx, int on);
+int serhip_profile_read(serhip_ctx* ctx, int kind, double* total_ms, int64_t* launches);
+
 /* ---- host-only helpers (no GPU touched; used by the CPU test-suite) ---- */
 
 /* Copy one host-built constant table of the fast plan into `out` (f32).

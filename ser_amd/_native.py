@@ -36,6 +36,8 @@ SIGNATURES: dict[str, tuple] = {
         [c_void_p, c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), c_int32, c_int, c_void_p, c_void_p],
     ),
     "serhip_whisper_logmel": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
+    "serhip_profile_enable": (c_int, [c_void_p, c_int]),
+    "serhip_profile_read": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
     "serhip_host_table": (c_int64, [c_int, c_int, c_int, POINTER(c_float), c_int64]),
     "serhip_frame_count": (c_int64, [c_int64]),
 }
@@ -120,6 +122,15 @@ class Context:
             plan = Plan(self, int(sample_rate), int(flags))
             self._plans[key] = plan
         return plan
+
+    def profile_enable(self, on: bool) -> None:
+        check(self._lib.serhip_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self, kind: int) -> tuple[float, int]:
+        """(summed milliseconds, launch count) of the recorded launches of ``kind``; clears them."""
+        ms, n = c_double(0.0), c_int64(0)
+        check(self._lib.serhip_profile_read(self.handle, int(kind), ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
 
     def close(self) -> None:
         if self._handle is not None:

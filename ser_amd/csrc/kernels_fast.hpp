@@ -22,7 +22,8 @@ constexpr int kWaves = 4;              // waves per workgroup in k_stft_frames
 constexpr int kFramesPerBlock = 16;    // STFT frames per workgroup
 constexpr int kBufC = 1088;            // complex slots of one wave's LDS buffer (16 rows x stride 68)
 constexpr int kMelWCap = 2304;         // capacity of the sparse mel weight stream
-constexpr int kPeakLdsCap = 6144;      // peaks staged in LDS by k_segment_finish
+constexpr int kPeakLdsCap = 3072;      // peaks staged in LDS by k_segment_finish
+constexpr int kChromaTableStride = 1025 * 12 + 4;  // floats per tuning in the chroma table ([k][12], 16-B rows)
 
 // per-segment descriptor (device copy of what the host planned)
 struct SegDesc {
@@ -44,7 +45,7 @@ struct PlanTables {
     const v2f* win;       // [16][64]  Hann pairs (w[128n1+2l], w[128n1+2l+1])
     const float* mel_w;   // sparse mel weights, filter-major
     const int4* mel_rng;  // [128] (first bin, count, offset into mel_w, 0)
-    const float* chroma;  // [101][12][kBinStride]
+    const float* chroma;  // [101][kChromaTableStride]: per tuning [bin][12]
     const float* dct;     // [40][128]
     const double* edges;  // [101] histogram edges np.linspace(-0.5, 0.5, 101)
     const double* mel_f;  // [130] mel band edges in Hz (generic path)
@@ -96,6 +97,7 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 // The parabolic shift is a double division of float32 sums, as numba evaluates the stencil.
 __device__ __forceinline__ v2f piptrack_peak(float sm, float s0, float sp, int i, double bin_hz_num,
                                              double n_fft_d) {
+#pragma clang fp contract(off)  // numpy / numba round every product and sum separately
     const float sum = sp + sm;
     const float dif = sp - sm;
     const double a = static_cast<double>(sum) - 2.0 * static_cast<double>(s0);
@@ -338,14 +340,14 @@ __device__ __forceinline__ int tuning_bin(float r, const double* __restrict__ ed
 }
 
 struct FinishShared {
-    float fb[kChroma * kBinStride];   // chroma filterbank of the selected tuning
+    float fb[kBins * kChroma + 4];    // chroma filterbank of the selected tuning, [bin][12]
     v2f peaks[kPeakLdsCap];
     unsigned hist[256];
     float red[64];
     int ired[8];
-    float lmean[kMels];
-    float melsum[2][kMels];
-    float lsum[2][kMels];
+    double lmean[kMels];
+    double melsum[2][kMels];
+    double lsum[2][kMels];
     float chroma_acc[4][16];
     unsigned sel_prefix, sel_k;
     int n_peaks;
@@ -382,15 +384,36 @@ __device__ float select_kth(FinishShared& sh, bool in_lds, const Scratch& sc, co
             if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
         });
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned cum = 0;
-            int b = 0;
-            for (; b < 255; ++b) {
-                if (cum + sh.hist[b] > k) break;
-                cum += sh.hist[b];
+        if (threadIdx.x < 64) {
+            // one wave locates the bucket holding rank k: 4 bins per lane, inclusive scan over lanes
+            const int l = threadIdx.x;
+            const unsigned c0 = sh.hist[4 * l], c1 = sh.hist[4 * l + 1], c2 = sh.hist[4 * l + 2], c3 = sh.hist[4 * l + 3];
+            const unsigned mine = c0 + c1 + c2 + c3;
+            unsigned incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o);
+                if (l >= o) incl += up;
             }
-            sh.sel_prefix = prefix | (static_cast<unsigned>(b) << shift);
-            sh.sel_k = k - cum;
+            const unsigned long long hit = __ballot(incl > k);
+            const int owner = hit ? __ffsll(static_cast<long long>(hit)) - 1 : 63;
+            if (l == owner) {
+                unsigned cum = incl - mine;
+                int b = 4 * l;
+                if (cum + c0 > k) {
+                } else if (cum + c0 + c1 > k) {
+                    cum += c0;
+                    b += 1;
+                } else if (cum + c0 + c1 + c2 > k) {
+                    cum += c0 + c1;
+                    b += 2;
+                } else {
+                    cum += c0 + c1 + c2;
+                    b += 3;
+                }
+                sh.sel_prefix = prefix | (static_cast<unsigned>(b) << shift);
+                sh.sel_k = k - cum;
+            }
         }
         __syncthreads();
         prefix = sh.sel_prefix;
@@ -407,7 +430,7 @@ __device__ void chroma_column_dev(int k, int n_fft, int sr, double tuning, float
 // ---------------------------------------------------------------------------------------
 // k_segment_finish: one workgroup (256 threads) per segment
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_segment_finish(const SegDesc* __restrict__ segs, PlanTables tb,
+__global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __restrict__ segs, PlanTables tb,
                                                         Scratch sc, float* __restrict__ out,
                                                         float* __restrict__ tuning_out, int out_dim) {
     __shared__ FinishShared sh;
@@ -428,10 +451,13 @@ __global__ __launch_bounds__(256) void k_segment_finish(const SegDesc* __restric
     if (want_mfcc || want_mel) {
         const int m = tid & 127, half = tid >> 7;
         const float* mel = sc.mel + static_cast<size_t>(sd.mel_base) * kMels;
-        float s = 0.0f, lmax = -INFINITY;
+        // time sums are accumulated in double (the reference's float32 pairwise sums are within
+        // rounding of the exact value; a float32 running sum here would not be)
+        double s = 0.0;
+        float lmax = -INFINITY;
         for (int t = half; t < sd.n_mel; t += 2) {
             const float v = mel[static_cast<size_t>(t) * kMels + m];
-            s += v;
+            s += static_cast<double>(v);
             lmax = fmaxf(lmax, 10.0f * log10f(fmaxf(1e-10f, v)));
         }
         sh.melsum[half][m] = s;
@@ -440,26 +466,26 @@ __global__ __launch_bounds__(256) void k_segment_finish(const SegDesc* __restric
         __syncthreads();
         lmax = fmaxf(fmaxf(sh.red[0], sh.red[1]), fmaxf(sh.red[2], sh.red[3]));
         const float floor_db = lmax - 80.0f;
-        float ls = 0.0f;
+        double ls = 0.0;
         if (want_mfcc) {
             for (int t = half; t < sd.n_mel; t += 2) {
                 const float v = mel[static_cast<size_t>(t) * kMels + m];
-                ls += fmaxf(10.0f * log10f(fmaxf(1e-10f, v)), floor_db);
+                ls += static_cast<double>(fmaxf(10.0f * log10f(fmaxf(1e-10f, v)), floor_db));
             }
         }
         sh.lsum[half][m] = ls;
         __syncthreads();
-        const float inv_t = 1.0f / static_cast<float>(sd.n_mel);
+        const double inv_t = 1.0 / static_cast<double>(sd.n_mel);
         if (tid < kMels) {
             sh.lmean[tid] = (sh.lsum[0][tid] + sh.lsum[1][tid]) * inv_t;
-            if (want_mel) orow[off_mel + tid] = (sh.melsum[0][tid] + sh.melsum[1][tid]) * inv_t;
+            if (want_mel) orow[off_mel + tid] = static_cast<float>((sh.melsum[0][tid] + sh.melsum[1][tid]) * inv_t);
         }
         __syncthreads();
         if (want_mfcc && tid < kMfcc) {
-            float acc = 0.0f;
+            double acc = 0.0;
             const float* d = tb.dct + tid * kMels;
-            for (int j = 0; j < kMels; ++j) acc = fmaf(d[j], sh.lmean[j], acc);
-            orow[off_mfcc + tid] = acc;
+            for (int j = 0; j < kMels; ++j) acc = fma(static_cast<double>(d[j]), sh.lmean[j], acc);
+            orow[off_mfcc + tid] = static_cast<float>(acc);
         }
     }
     if (want_contrast && tid < 7) orow[off_contrast + tid] = 0.0f;
@@ -521,58 +547,72 @@ __global__ __launch_bounds__(256) void k_segment_finish(const SegDesc* __restric
     }
     if (tuning_out && tid == 0) tuning_out[sd.out_row] = static_cast<float>(tb.edges[tuning_idx]);
 
-    // ---- chroma filterbank of that tuning -> LDS
+    // ---- chroma filterbank of that tuning -> LDS, bin-major [k][12] (3 x ds_read_b128 per bin)
     if (sd.n_fft == kNfft) {
-        const float4* src = reinterpret_cast<const float4*>(tb.chroma + static_cast<size_t>(tuning_idx) * kChroma * kBinStride);
+        const float4* src = reinterpret_cast<const float4*>(tb.chroma + static_cast<size_t>(tuning_idx) * kChromaTableStride);
         float4* dst = reinterpret_cast<float4*>(sh.fb);
-        for (int i = tid; i < kChroma * kBinStride / 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = tid; i < kBins * kChroma / 4; i += blockDim.x) dst[i] = src[i];
     } else {
         const double tuning = tb.edges[tuning_idx];
         for (int k = tid; k < nbins; k += blockDim.x) {
             float col[12];
             chroma_column_dev(k, sd.n_fft, tb.sample_rate, tuning, col);
 #pragma unroll
-            for (int c = 0; c < 12; ++c) sh.fb[c * kBinStride + k] = col[c];
+            for (int c = 0; c < 12; ++c) sh.fb[k * kChroma + c] = col[c];
         }
     }
     __syncthreads();
 
-    // ---- chroma = fb @ |STFT|, per-frame inf-norm, time mean.  Two frames per wave pass.
-    float acc_c = 0.0f;  // lanes 0..11 of each wave accumulate chroma class `lane`
+    // ---- chroma = fb @ |STFT|, per-frame inf-norm, time mean.
+    // A wave takes 4 frames per pass: lane l holds bins l, l+64, ... of each frame, every
+    // filterbank weight read from LDS is applied to the 4 frames, and the 4 x 16 partial sums
+    // are reduced with a halving butterfly (63 shuffles) that leaves lane l with the complete
+    // sum of (frame l>>4, chroma class l&15).
     const float tiny = 1.17549435e-38f;
-    for (int t0 = 2 * wave; t0 < sd.n_stft; t0 += 8) {
-        const bool two = (t0 + 1) < sd.n_stft;
-        const float* m0 = sc.mags + (static_cast<size_t>(sd.stft_base) + t0) * kBinStride;
-        const float* m1 = two ? m0 + kBinStride : m0;
-        float a0[12], a1[12];
+    const int fslot = lane >> 4;
+    float acc_c = 0.0f;
+    for (int t0 = 4 * wave; t0 < sd.n_stft; t0 += 16) {
+        const float* mrow[4];
 #pragma unroll
-        for (int c = 0; c < 12; ++c) a0[c] = a1[c] = 0.0f;
+        for (int f = 0; f < 4; ++f)
+            mrow[f] = sc.mags + (static_cast<size_t>(sd.stft_base) + min(t0 + f, sd.n_stft - 1)) * kBinStride;
+        float v[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = 0.0f;
         for (int k = lane; k < nbins; k += 64) {
-            const float x0 = m0[k], x1 = m1[k];
+            float x[4];
 #pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                const float w = sh.fb[c * kBinStride + k];
-                a0[c] = fmaf(w, x0, a0[c]);
-                a1[c] = fmaf(w, x1, a1[c]);
+            for (int f = 0; f < 4; ++f) x[f] = mrow[f][k];
+            const float4* wp = reinterpret_cast<const float4*>(sh.fb + k * kChroma);
+            const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int c = 0; c < 12; ++c) v[f * 16 + c] = fmaf(w[c], x[f], v[f * 16 + c]);
+        }
+        // halving butterfly: after the stage with offset o, lane keeps the half selected by (lane & o)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const bool up = (lane & o) != 0;
+#pragma unroll
+            for (int i = 0; i < o; ++i) {
+                const float keep = up ? v[i + o] : v[i];
+                const float send = up ? v[i] : v[i + o];
+                v[i] = keep + __shfl_xor(send, o);
             }
         }
-        float mx0 = 0.0f, mx1 = 0.0f, mine0 = 0.0f, mine1 = 0.0f;
+        // v[0] = raw chroma of (frame t0 + fslot, class lane & 15); classes 12..15 are zero pads
+        float raw = v[0];
+        float mx = fabsf(raw);
 #pragma unroll
-        for (int c = 0; c < 12; ++c) {
-            const float r0 = wave_sum(a0[c]);
-            const float r1 = wave_sum(a1[c]);
-            mx0 = fmaxf(mx0, fabsf(r0));
-            mx1 = fmaxf(mx1, fabsf(r1));
-            if (lane == c) {
-                mine0 = r0;
-                mine1 = r1;
-            }
-        }
-        if (mx0 < tiny) mx0 = 1.0f;
-        if (mx1 < tiny) mx1 = 1.0f;
-        acc_c += mine0 / mx0;
-        if (two) acc_c += mine1 / mx1;
+        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (mx < tiny) mx = 1.0f;
+        if (t0 + fslot < sd.n_stft) acc_c += raw / mx;
     }
+    // combine the 4 frame slots of the wave, then the waves
+    acc_c += __shfl_xor(acc_c, 16);
+    acc_c += __shfl_xor(acc_c, 32);
     if (lane < 16) sh.chroma_acc[wave][lane] = acc_c;
     __syncthreads();
     if (tid < kChroma) {

@@ -172,12 +172,25 @@ __global__ __launch_bounds__(256) void k_dft_frames(const float* __restrict__ au
     if (tid == 0) sc.peak_cnt[row] = s_cnt;
 }
 
+// correctly rounded double sqrt: the device sqrt is within 1 ulp; one Markstein correction step
+// (exact residual by fma, then a fused update) rounds it the way IEEE-754 / numpy does
+__device__ __forceinline__ double sqrt_rn(double x) {
+    double y = sqrt(x);
+    if (x > 0.0 && y < 1.0e300) {
+        const double r = fma(-y, y, x);
+        const double h = 0.5 / y;
+        y = fma(r, h, y);
+    }
+    return y;
+}
+
 // out[w, c]        = mean over rows [lo, hi) of emb[:, c]                     (both modes)
 // out[w, dim + c]  = population std (mode 0 only), numpy's two-pass formula in float64
 __global__ __launch_bounds__(256) void k_pool_windows(const float* __restrict__ emb, int dim,
                                                       const int* __restrict__ win_lo,
                                                       const int* __restrict__ win_hi, int n_win, int mode,
                                                       double* __restrict__ out) {
+#pragma clang fp contract(off)  // numpy rounds every product and sum separately
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = blockIdx.y;
     if (c >= dim || w >= n_win) return;
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(256) void k_pool_windows(const float* __restrict__ 
     }
     double* orow = out + static_cast<size_t>(w) * 2 * dim;
     orow[c] = mean;
-    orow[dim + c] = sqrt(v / static_cast<double>(n));
+    orow[dim + c] = sqrt_rn(v / static_cast<double>(n));
 }
 
 }  // namespace serhip

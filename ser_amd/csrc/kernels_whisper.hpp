@@ -22,26 +22,33 @@ constexpr int kWHalf = 200;          // packed complex points per frame
 constexpr int kWTile = 64;           // frames per workgroup
 constexpr int kWMelWCap = 1024;      // sparse mel taps (80 mels: ~400, 128 mels: ~500)
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2d cmuld(v2d a, v2d b) {
+    return v2d{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+
 struct WhisperTables {
-    const v2f* tw200;    // [200] W_200^m
-    const v2f* tw400;    // [201] W_400^k
-    const float* win;    // [400]
+    const v2d* tw200;    // [200] W_200^m   (double: the 1e-5 gate is against a float64 STFT)
+    const v2d* tw400;    // [201] W_400^k
+    const double* win;   // [400]
     const float* mel_w;  // sparse taps
     const int4* mel_rng; // [n_mels] (first bin, count, offset, 0)
     int mel_nnz;
     int n_mels;
 };
 
-// pass 1: log10(max(mel, 1e-10)) into out[clip][m][t] and the running clip maximum
+// pass 1: log10(max(mel, 1e-10)) into out[clip][m][t] and the running clip maximum.
+// The 400-point DFT is accumulated in double: bins 80 dB below the clip maximum still have to
+// agree with a float64 STFT to ~1e-4 relative, which a float32 transform does not deliver.
 __global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict__ audio, long long n_samples,
                                                         int n_frames, WhisperTables wt, float* __restrict__ out,
                                                         unsigned* __restrict__ clip_max) {
-    __shared__ v2f s_tw200[kWHalf];
-    __shared__ v2f s_tw400[kWBins + 3];
-    __shared__ float s_win[kWNfft];
+    __shared__ v2d s_tw200[kWHalf];
+    __shared__ v2d s_tw400[kWBins + 1];
+    __shared__ double s_win[kWNfft];
     __shared__ float s_melw[kWMelWCap];
-    __shared__ v2f s_z[4][kWHalf];
-    __shared__ v2f s_y[4][kWHalf];
+    __shared__ v2d s_z[4][kWHalf];
+    __shared__ v2d s_y[4][kWHalf];
     __shared__ float s_p[4][kWBins + 3];
     __shared__ float s_tile[128][kWTile + 1];
     __shared__ float s_red[4];
@@ -59,8 +66,8 @@ __global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict_
 
     const int4 rng0 = (lane < wt.n_mels) ? wt.mel_rng[lane] : int4{0, 0, 0, 0};
     const int4 rng1 = (lane + 64 < wt.n_mels) ? wt.mel_rng[lane + 64] : int4{0, 0, 0, 0};
-    v2f* z = s_z[wave];
-    v2f* y = s_y[wave];
+    v2d* z = s_z[wave];
+    v2d* y = s_y[wave];
     float* p = s_p[wave];
     float vmax = -INFINITY;
 
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict_
                 if (s0 >= n_samples) s0 = 2 * (n_samples - 1) - s0;
                 if (s1 < 0) s1 = -s1;
                 if (s1 >= n_samples) s1 = 2 * (n_samples - 1) - s1;
-                z[n] = v2f{x[s0] * s_win[2 * n], x[s1] * s_win[2 * n + 1]};
+                z[n] = v2d{static_cast<double>(x[s0]) * s_win[2 * n], static_cast<double>(x[s1]) * s_win[2 * n + 1]};
             }
         }
         wave_lds_sync();
@@ -88,28 +95,28 @@ __global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict_
             const int o = lane + 64 * i;
             if (o < kWHalf) {
                 const int k1 = o >> 3, n2 = o & 7;
-                v2f acc = v2f{0.0f, 0.0f};
+                v2d acc = v2d{0.0, 0.0};
                 int e = 0;  // (8 * n1 * k1) mod 200
                 for (int n1 = 0; n1 < 25; ++n1) {
-                    acc += cmul(z[8 * n1 + n2], s_tw200[e]);
+                    acc += cmuld(z[8 * n1 + n2], s_tw200[e]);
                     e += 8 * k1;
                     if (e >= kWHalf) e -= kWHalf;
                 }
-                y[o] = cmul(acc, s_tw200[n2 * k1]);
+                y[o] = cmuld(acc, s_tw200[n2 * k1]);
             }
         }
         wave_lds_sync();
         // ---- step 2: Z[k1 + 25 k2] = sum_{n2<8} Y'[k1][n2] W_8^(n2 k2)
-        v2f zk[4];
+        v2d zk[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int o = lane + 64 * i;
-            zk[i] = v2f{0.0f, 0.0f};
+            zk[i] = v2d{0.0, 0.0};
             if (o < kWHalf) {
                 const int k1 = o % 25, k2 = o / 25;
-                v2f acc = v2f{0.0f, 0.0f};
+                v2d acc = v2d{0.0, 0.0};
 #pragma unroll
-                for (int n2 = 0; n2 < 8; ++n2) acc += cmul(y[k1 * 8 + n2], s_tw200[(25 * n2 * k2) % kWHalf]);
+                for (int n2 = 0; n2 < 8; ++n2) acc += cmuld(y[k1 * 8 + n2], s_tw200[(25 * n2 * k2) % kWHalf]);
                 zk[i] = acc;
             }
         }
@@ -125,12 +132,12 @@ __global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict_
         for (int i = 0; i < 4; ++i) {
             const int k = lane + 64 * i;
             if (k < kWBins) {
-                const v2f za = z[k % kWHalf];
-                const v2f zb = z[(kWHalf - k) % kWHalf];
-                const v2f e2 = v2f{za.x + zb.x, za.y - zb.y};
-                const v2f o2 = v2f{za.y + zb.y, zb.x - za.x};
-                const v2f xk = 0.5f * (e2 + cmul(o2, s_tw400[k]));
-                p[k] = xk.x * xk.x + xk.y * xk.y;
+                const v2d za = z[k % kWHalf];
+                const v2d zb = z[(kWHalf - k) % kWHalf];
+                const v2d e2 = v2d{za.x + zb.x, za.y - zb.y};
+                const v2d o2 = v2d{za.y + zb.y, zb.x - za.x};
+                const v2d xk = 0.5 * (e2 + cmuld(o2, s_tw400[k]));
+                p[k] = static_cast<float>(xk.x * xk.x + xk.y * xk.y);
             }
         }
         wave_lds_sync();

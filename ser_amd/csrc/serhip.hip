@@ -97,10 +97,9 @@ void build_host_tables(int sr, HostTables& h, bool with_chroma) {
     h.mel_f = mel_edges(kMels, static_cast<double>(sr) / 2);
     piptrack_bin_range(sr, kNfft, &h.kmin, &h.kmax);
     if (with_chroma) {
-        h.chroma.assign(static_cast<size_t>(kTunings) * kChroma * kBinStride, 0.0f);
+        h.chroma.assign(static_cast<size_t>(kTunings) * kChromaTableStride, 0.0f);
         for (int i = 0; i < kTunings; ++i)
-            chroma_filterbank(sr, kNfft, h.edges[i], h.chroma.data() + static_cast<size_t>(i) * kChroma * kBinStride,
-                              kBinStride);
+            chroma_filterbank(sr, kNfft, h.edges[i], h.chroma.data() + static_cast<size_t>(i) * kChromaTableStride);
     }
 }
 
@@ -116,6 +115,14 @@ struct serhip_ctx {
     size_t chunk_frames = 0;     // frames of scratch per chunk (0 = default)
     void* whisper_blob[2] = {nullptr, nullptr};   // tables for n_mels 80 / 128
     WhisperTables whisper_tb[2] = {};
+    // optional per-kernel timing with HIP events (serhip_profile_*)
+    bool profiling = false;
+    struct Timed {
+        int kind;
+        hipEvent_t start, stop;
+    };
+    std::vector<Timed> timed;          // launches recorded since the last read
+    std::vector<hipEvent_t> event_pool;
 };
 
 struct serhip_plan {
@@ -195,21 +202,51 @@ Scratch scratch_at(char* base, const ScratchLayout& l, int peak_cap) {
 
 constexpr int kGenericPeakCap = 520;  // > (1 + 2047/2) / 2 local maxima per frame
 
+hipEvent_t take_event(serhip_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// brackets one kernel launch with events on its own stream when profiling is on
+struct LaunchTimer {
+    serhip_ctx* ctx;
+    hipStream_t stream;
+    hipEvent_t start = nullptr, stop = nullptr;
+    int kind;
+    LaunchTimer(serhip_ctx* c, int k, hipStream_t s) : ctx(c), stream(s), kind(k) {
+        if (!ctx->profiling) return;
+        start = take_event(ctx);
+        stop = take_event(ctx);
+        if (start && stop) (void)hipEventRecord(start, stream);
+    }
+    ~LaunchTimer() {
+        if (!start || !stop) return;
+        (void)hipEventRecord(stop, stream);
+        ctx->timed.push_back({kind, start, stop});
+    }
+};
+
 // constant tables of the Whisper front end (16 kHz, n_fft 400), built once per n_mels
 int ensure_whisper_tables(serhip_ctx* ctx, int n_mels) {
     const int slot = (n_mels == 80) ? 0 : 1;
     if (ctx->whisper_blob[slot]) return SERHIP_OK;
-    std::vector<v2f> tw200(kWHalf), tw400(kWBins);
+    std::vector<v2d> tw200(kWHalf), tw400(kWBins);
     for (int m = 0; m < kWHalf; ++m) {
         const double a = -2.0 * kPi * m / 200.0;
-        tw200[m] = v2f{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
+        tw200[m] = v2d{std::cos(a), std::sin(a)};
     }
     for (int k = 0; k < kWBins; ++k) {
         const double a = -2.0 * kPi * k / 400.0;
-        tw400[k] = v2f{static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a))};
+        tw400[k] = v2d{std::cos(a), std::sin(a)};
     }
-    std::vector<float> win(kWNfft);
-    for (int j = 0; j < kWNfft; ++j) win[j] = static_cast<float>(0.5 - 0.5 * std::cos(2.0 * kPi * j / 400.0));
+    std::vector<double> win(kWNfft);
+    for (int j = 0; j < kWNfft; ++j) win[j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / 400.0);
     const std::vector<float> dense = mel_filterbank(16000, kWNfft, n_mels);
     std::vector<float> mel_w;
     std::vector<int4> rng(n_mels, int4{0, 0, 0, 0});
@@ -232,13 +269,13 @@ int ensure_whisper_tables(serhip_ctx* ctx, int n_mels) {
         o = align_up(o + bytes, 256);
         return at;
     };
-    const size_t o200 = take(tw200.size() * sizeof(v2f)), o400 = take(tw400.size() * sizeof(v2f)),
-                 owin = take(win.size() * sizeof(float)), omw = take(std::max<size_t>(mel_w.size(), 1) * sizeof(float)),
+    const size_t o200 = take(tw200.size() * sizeof(v2d)), o400 = take(tw400.size() * sizeof(v2d)),
+                 owin = take(win.size() * sizeof(double)), omw = take(std::max<size_t>(mel_w.size(), 1) * sizeof(float)),
                  orng = take(rng.size() * sizeof(int4));
     std::vector<char> blob(o, 0);
-    std::memcpy(blob.data() + o200, tw200.data(), tw200.size() * sizeof(v2f));
-    std::memcpy(blob.data() + o400, tw400.data(), tw400.size() * sizeof(v2f));
-    std::memcpy(blob.data() + owin, win.data(), win.size() * sizeof(float));
+    std::memcpy(blob.data() + o200, tw200.data(), tw200.size() * sizeof(v2d));
+    std::memcpy(blob.data() + o400, tw400.data(), tw400.size() * sizeof(v2d));
+    std::memcpy(blob.data() + owin, win.data(), win.size() * sizeof(double));
     if (!mel_w.empty()) std::memcpy(blob.data() + omw, mel_w.data(), mel_w.size() * sizeof(float));
     std::memcpy(blob.data() + orng, rng.data(), rng.size() * sizeof(int4));
     void* dev = nullptr;
@@ -249,9 +286,9 @@ int ensure_whisper_tables(serhip_ctx* ctx, int n_mels) {
     }
     char* d = static_cast<char*>(dev);
     WhisperTables& wt = ctx->whisper_tb[slot];
-    wt.tw200 = reinterpret_cast<const v2f*>(d + o200);
-    wt.tw400 = reinterpret_cast<const v2f*>(d + o400);
-    wt.win = reinterpret_cast<const float*>(d + owin);
+    wt.tw200 = reinterpret_cast<const v2d*>(d + o200);
+    wt.tw400 = reinterpret_cast<const v2d*>(d + o400);
+    wt.win = reinterpret_cast<const double*>(d + owin);
     wt.mel_w = reinterpret_cast<const float*>(d + omw);
     wt.mel_rng = reinterpret_cast<const int4*>(d + orng);
     wt.mel_nnz = static_cast<int>(mel_w.size());
@@ -322,6 +359,11 @@ void serhip_destroy(serhip_ctx* ctx) {
         if (b) (void)hipFree(b);
     if (ctx->staging) (void)hipHostFree(ctx->staging);
     if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
+    for (const serhip_ctx::Timed& t : ctx->timed) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -537,14 +579,26 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
         const SegDesc* dd = d_descs + c.first;
         if (!c.generic) {
             const dim3 grid((c.max_frames + kFramesPerBlock - 1) / kFramesPerBlock, static_cast<unsigned>(c.count));
-            hipLaunchKernelGGL(k_stft_frames, grid, dim3(kWaves * 64), 0, stream, audio_dev, dd, plan->tb, sf);
-            hipLaunchKernelGGL(k_segment_finish, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
-                               plan->tb, sf, out_dev, tuning_dev, plan->dim);
+            {
+                LaunchTimer lt(ctx, SERHIP_KERNEL_STFT_FRAMES, stream);
+                hipLaunchKernelGGL(k_stft_frames, grid, dim3(kWaves * 64), 0, stream, audio_dev, dd, plan->tb, sf);
+            }
+            {
+                LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream);
+                hipLaunchKernelGGL(k_segment_finish, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
+                                   plan->tb, sf, out_dev, tuning_dev, plan->dim);
+            }
         } else {
             const dim3 grid(static_cast<unsigned>(c.max_frames), static_cast<unsigned>(c.count));
-            hipLaunchKernelGGL(k_dft_frames, grid, dim3(256), 0, stream, audio_dev, dd, plan->tb, sg);
-            hipLaunchKernelGGL(k_segment_finish, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
-                               plan->tb, sg, out_dev, tuning_dev, plan->dim);
+            {
+                LaunchTimer lt(ctx, SERHIP_KERNEL_DFT_FRAMES, stream);
+                hipLaunchKernelGGL(k_dft_frames, grid, dim3(256), 0, stream, audio_dev, dd, plan->tb, sg);
+            }
+            {
+                LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream);
+                hipLaunchKernelGGL(k_segment_finish, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
+                                   plan->tb, sg, out_dev, tuning_dev, plan->dim);
+            }
         }
     }
     HIP_TRY(hipGetLastError());
@@ -597,6 +651,37 @@ int serhip_whisper_logmel(serhip_ctx* ctx, const float* audio_dev, int32_t n_cli
     return whisper_logmel_launch(ctx, audio_dev, n_clips, n_samples, n_mels, out_dev, stream);
 }
 
+int serhip_profile_enable(serhip_ctx* ctx, int on) {
+    if (!ctx) return fail(SERHIP_E_INVALID, "serhip_profile_enable: ctx is NULL");
+    ctx->profiling = on != 0;
+    return SERHIP_OK;
+}
+
+int serhip_profile_read(serhip_ctx* ctx, int kind, double* total_ms, int64_t* launches) {
+    if (!ctx || !total_ms || !launches) return fail(SERHIP_E_INVALID, "serhip_profile_read: NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double sum = 0.0;
+    int64_t n = 0;
+    std::vector<serhip_ctx::Timed> keep;
+    for (const serhip_ctx::Timed& t : ctx->timed) {
+        if (t.kind != kind) {
+            keep.push_back(t);
+            continue;
+        }
+        HIP_TRY(hipEventSynchronize(t.stop));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+        sum += ms;
+        n += 1;
+        ctx->event_pool.push_back(t.start);
+        ctx->event_pool.push_back(t.stop);
+    }
+    ctx->timed.swap(keep);
+    *total_ms = sum;
+    *launches = n;
+    return SERHIP_OK;
+}
+
 int64_t serhip_host_table(int sample_rate, int which, int arg, float* out, int64_t out_cap) {
     if (sample_rate <= 0) return fail(SERHIP_E_INVALID, "serhip_host_table: sample_rate must be positive");
     std::vector<float> v;
@@ -611,12 +696,11 @@ int64_t serhip_host_table(int sample_rate, int which, int arg, float* out, int64
             break;
         case 2: {
             if (arg < 0 || arg >= kTunings) return fail(SERHIP_E_INVALID, "serhip_host_table: tuning index out of range");
-            std::vector<float> padded(static_cast<size_t>(kChroma) * kBinStride, 0.0f);
-            chroma_filterbank(sample_rate, kNfft, tuning_edge(arg), padded.data(), kBinStride);
+            std::vector<float> bin_major(static_cast<size_t>(kBins) * kChroma, 0.0f);
+            chroma_filterbank(sample_rate, kNfft, tuning_edge(arg), bin_major.data());
             v.resize(static_cast<size_t>(kChroma) * kBins);
             for (int c = 0; c < kChroma; ++c)
-                std::copy(padded.begin() + static_cast<size_t>(c) * kBinStride,
-                          padded.begin() + static_cast<size_t>(c) * kBinStride + kBins, v.begin() + static_cast<size_t>(c) * kBins);
+                for (int k = 0; k < kBins; ++k) v[static_cast<size_t>(c) * kBins + k] = bin_major[static_cast<size_t>(k) * kChroma + c];
             break;
         }
         case 3:

@@ -146,14 +146,10 @@ inline void chroma_column(int k, int n_fft, int sr, double tuning, float* out12)
     }
 }
 
-// [12, stride] row-major f32 chroma filterbank for one tuning (columns 0..bins-1 valid)
-inline void chroma_filterbank(int sr, int n_fft, double tuning, float* out, int stride) {
+// bin-major [bins][12] f32 chroma filterbank for one tuning (the transpose of librosa's [12, bins])
+inline void chroma_filterbank(int sr, int n_fft, double tuning, float* out) {
     const int bins = 1 + n_fft / 2;
-    float col[12];
-    for (int k = 0; k < bins; ++k) {
-        chroma_column(k, n_fft, sr, tuning, col);
-        for (int c = 0; c < 12; ++c) out[static_cast<size_t>(c) * stride + k] = col[c];
-    }
+    for (int k = 0; k < bins; ++k) chroma_column(k, n_fft, sr, tuning, out + static_cast<size_t>(k) * 12);
 }
 
 // scipy.fft.dct(type=2, norm='ortho') matrix rows 0..n_out-1 over n_in inputs, f32

@@ -1,0 +1,65 @@
+"""Multi-GPU sharding of the featurisation: one process per GPU, contiguous shards by
+segment index, one all-gather (RCCL over xGMI; gloo in the CPU tests) that assembles
+the training feature matrix on every rank.
+
+The reference has no distributed code; its only fan-out is the ``multiprocessing.Pool``
+over files of ``ser/_internal/data/data_loader.py:368-379``, which proves the units are
+independent (``imap_unordered``).  Segments never exchange data, so the gather is the
+single collective of the path.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(n_items: int, world_size: int) -> np.ndarray:
+    """``world_size + 1`` boundaries of contiguous shards: rank r owns [b[r], b[r+1]).
+
+    Every rank gets ``ceil(n / world)`` items except the trailing ranks, which may get
+    fewer (or none) -- the gather pads to the common row count.
+    """
+    if world_size <= 0:
+        raise ValueError("world_size must be positive")
+    per = -(-int(n_items) // int(world_size)) if n_items > 0 else 0
+    return np.minimum(np.arange(world_size + 1, dtype=np.int64) * per, int(n_items))
+
+
+def shard_range(n_items: int, rank: int, world_size: int) -> tuple[int, int]:
+    b = shard_bounds(n_items, world_size)
+    return int(b[rank]), int(b[rank + 1])
+
+
+def all_gather_rows(local, n_total: int, *, group=None):
+    """Gather row shards ``[rows_r, D]`` (torch tensors, same device/dtype on all ranks) into
+    the full ``[n_total, D]`` matrix on every rank, in rank order.
+
+    Shards are padded to ``ceil(n_total / world)`` rows so a single
+    ``all_gather_into_tensor`` (one RCCL collective) moves them; padding rows are dropped.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if int(local.shape[0]) != int(n_total):
+            raise ValueError("single-process gather: local rows must equal n_total")
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    bounds = shard_bounds(n_total, world)
+    per = int(bounds[1] - bounds[0]) if world > 0 else 0
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    if int(local.shape[0]) != hi - lo:
+        raise ValueError(f"rank {rank}: expected {hi - lo} rows, got {int(local.shape[0])}")
+    dim = int(local.shape[1])
+    send = local
+    if hi - lo != per:
+        send = torch.zeros((per, dim), dtype=local.dtype, device=local.device)
+        send[: hi - lo] = local
+    send = send.contiguous()
+    full = torch.empty((world * per, dim), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, send, group=group)
+    if world * per == n_total:
+        return full
+    pieces = [full[r * per : r * per + int(bounds[r + 1] - bounds[r])] for r in range(world)]
+    return torch.cat(pieces, dim=0)

@@ -62,3 +62,31 @@ def write_wav_pcm16(path, samples_int16: np.ndarray, sample_rate: int) -> None:
         w.setsampwidth(2)
         w.setframerate(sample_rate)
         w.writeframes(np.asarray(samples_int16, dtype="<i2").tobytes())
+
+
+def harmonic_clips_torch(seed: int, n_clips: int, n_samples: int, device, sample_rate: int = 16000):
+    """Same family as :func:`harmonic_clips`, generated on ``device`` with torch (bench inputs:
+    nothing is read from disk and nothing crosses PCIe).  Returns ``[n_clips, n_samples]`` float32."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    out = torch.empty((n_clips, n_samples), dtype=torch.float32, device=device)
+    t = torch.arange(n_samples, dtype=torch.float32, device=device) / float(sample_rate)
+    step = 512
+    for lo in range(0, n_clips, step):
+        n = min(step, n_clips - lo)
+
+        def u(a, b, *shape):
+            return a + (b - a) * torch.rand((n, *shape), generator=g, device=device)
+
+        f0 = u(80.0, 400.0, 1)
+        n_h = torch.randint(3, 7, (n, 1), generator=g, device=device)
+        x = torch.zeros((n, n_samples), dtype=torch.float32, device=device)
+        for h in range(1, 7):
+            amp = u(0.3, 1.0, 1) / h * (n_h >= h)
+            x += amp * torch.sin(2.0 * torch.pi * f0 * h * t[None, :] + u(0.0, 2 * torch.pi, 1))
+        env = 0.6 + 0.4 * torch.sin(2.0 * torch.pi * u(0.5, 4.0, 1) * t[None, :] + u(0.0, 2 * torch.pi, 1))
+        x = x * env + 0.01 * torch.randn((n, n_samples), generator=g, device=device)
+        out[lo : lo + n] = x / x.abs().amax(dim=1, keepdim=True)
+    return out

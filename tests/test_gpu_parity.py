@@ -1,0 +1,363 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerances are BASELINE.md's parity gates (tests/parity_utils.py): log-mel/MFCC rtol 1e-4
++ atol 2e-3; mel power and chroma rtol 1e-4 + atol 1e-6*max; contrast exactly 0; tuning
+estimate exactly equal on these seeded inputs.
+"""
+
+import numpy as np
+import pytest
+
+from parity_utils import CHROMA, MEL, MFCC, assert_features_close
+
+pytestmark = pytest.mark.gpu
+
+SR = 16000
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ser_amd.engine import get_engine
+
+    return get_engine()
+
+
+@pytest.fixture(scope="module")
+def flags():
+    from ser_amd import FeatureFlags
+
+    return FeatureFlags(tonnetz=False)
+
+
+def oracle_rows(audio, offs, lens, sr=SR, oflags=None):
+    from oracle import ser_fast_path as ofp
+
+    rows, tunings = [], []
+    for o, n in zip(offs, lens):
+        v, dbg = ofp.extract_feature_from_signal(audio[o : o + n], sr, flags=oflags, return_debug=True)
+        rows.append(v)
+        tunings.append(dbg.get("tuning", 0.0))
+    return np.asarray(rows), np.asarray(tunings)
+
+
+def gpu_rows(engine, flags, audio, offs, lens, sr=SR):
+    out, tun = engine.features(audio, offs, lens, sr, flags, return_tuning=True)
+    return out.cpu().numpy().astype(np.float64), tun.cpu().numpy().astype(np.float64)
+
+
+def test_loaded_native_library(engine):
+    from ser_amd import _native
+
+    assert _native.LIB_PATH.exists()
+    assert _native.load_library().serhip_version() >= 100
+
+
+def test_config3_clips_batch(engine, flags):
+    """Config 3 shape (3 s clips @16 kHz, harmonics + noise), 24 clips."""
+    from ser_amd.synth import harmonic_clips
+
+    clips = harmonic_clips(1234, 24, 48000)
+    audio = clips.reshape(-1)
+    offs = [i * 48000 for i in range(24)]
+    lens = [48000] * 24
+    got, tun = gpu_rows(engine, flags, audio, offs, lens)
+    want, wtun = oracle_rows(audio, offs, lens)
+    np.testing.assert_allclose(tun, wtun, atol=1e-6)
+    assert_features_close(got, want)
+
+
+def test_config1_sample_wav_windows(engine, flags):
+    """Config 1: 69 937-sample recording -> 3 s / 1 s windows through HandcraftedBackend."""
+    from oracle import ser_fast_path as ofp
+    from ser_amd import HandcraftedBackend
+    from ser_amd.synth import sample_wav_like
+
+    audio = sample_wav_like()
+    enc = HandcraftedBackend(feature_flags=flags).encode_sequence(audio, SR)
+    ref, starts, ends = ofp.encode_sequence(audio, SR)
+    assert enc.embeddings.dtype == np.float32 and enc.embeddings.shape == (5, 187)
+    np.testing.assert_array_equal(enc.frame_start_seconds, starts)
+    np.testing.assert_array_equal(enc.frame_end_seconds, ends)
+    assert enc.backend_id == "handcrafted"
+    assert_features_close(enc.embeddings, ref)
+
+
+def test_config2_synthetic_ravdess(engine, flags):
+    """Config 2: the 16 PCM16 sine clips of the synthetic RAVDESS generator, whole-clip vectors."""
+    from oracle import ser_fast_path as ofp
+    from ser_amd import HandcraftedBackend
+    from ser_amd.audio_io import prepare_audio_buffer
+    from ser_amd.synth import ravdess_sine_clip
+
+    clips = [prepare_audio_buffer(ravdess_sine_clip(a, e)) for a in (1, 2) for e in range(1, 9)]
+    ref_clip = ofp.prepare_audio_buffer(ofp.synthetic_ravdess_clip(2, 5))
+    np.testing.assert_array_equal(clips[8 + 4], ref_clip)
+    got = HandcraftedBackend(feature_flags=flags).extract_vectors(clips, SR)
+    want = np.asarray([ofp.extract_vector(c, SR) for c in clips])
+    assert got.dtype == np.float64 and got.shape == (16, 187)
+    assert_features_close(got, want)
+
+
+def test_ragged_unaligned_and_short_segments(engine, flags):
+    """Ragged lengths, odd offsets, and every n_fft regime: N<512 (padded), 512<=N<2048
+    (n_fft = N, odd and even, direct DFT kernel), N = 2048, N just above."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(40000).astype(np.float32)
+    x /= np.abs(x).max()
+    offs = [0, 1, 4001, 100, 7, 0, 10, 33, 500, 77, 3, 9]
+    lens = [2048, 2049, 5937, 20000, 29993, 100, 512, 1023, 1500, 2047, 1, 513]
+    got, tun = gpu_rows(engine, flags, x, offs, lens)
+    want, wtun = oracle_rows(x, offs, lens)
+    np.testing.assert_allclose(tun, wtun, atol=1e-6)
+    assert_features_close(got, want)
+
+
+def test_silence_and_constant(engine, flags):
+    z = np.zeros(9000, np.float32)
+    got, tun = gpu_rows(engine, flags, z, [0, 100], [9000, 1000])
+    want, _ = oracle_rows(z, [0, 100], [9000, 1000])
+    assert tun.tolist() == [0.0, 0.0]
+    assert_features_close(got, want)
+    assert got[0, 0] == pytest.approx(-1131.3708, rel=1e-6)   # -100 dB * sqrt(128)
+    assert not got[:, CHROMA].any() and not got[:, MEL].any()
+
+
+def test_other_sample_rates(engine, flags):
+    from ser_amd.synth import harmonic_clip
+
+    for sr in (22050, 44100, 48000):
+        a = harmonic_clip(np.random.default_rng(sr), 3 * sr // 2, sr)
+        got, tun = gpu_rows(engine, flags, a, [0], [a.size], sr=sr)
+        want, wtun = oracle_rows(a, [0], [a.size], sr=sr)
+        np.testing.assert_allclose(tun, wtun, atol=1e-6)
+        assert_features_close(got, want)
+
+
+def test_flag_subsets(engine, flags):
+    """Every block is computed identically whatever the other flags are; order mfcc|chroma|mel|contrast."""
+    from ser_amd import FeatureFlags
+    from ser_amd.synth import harmonic_clips
+
+    audio = harmonic_clips(77, 2, 30000).reshape(-1)
+    offs, lens = [0, 30000], [30000, 30000]
+    full = engine.features(audio, offs, lens, SR, flags).cpu().numpy()
+    blocks = {"mfcc": MFCC, "chroma": CHROMA, "mel": MEL, "contrast": slice(180, 187)}
+    for names in (("mfcc",), ("mel",), ("chroma",), ("mfcc", "mel"), ("chroma", "contrast"), ("contrast",)):
+        fl = FeatureFlags(**{k: (k in names) for k in blocks}, tonnetz=False)
+        out = engine.features(audio, offs, lens, SR, fl).cpu().numpy()
+        want = np.concatenate([full[:, blocks[k]] for k in blocks if k in names], axis=1)
+        np.testing.assert_array_equal(out, want)
+    empty = engine.features(audio, [0], [30000], SR, FeatureFlags(False, False, False, False, False))
+    assert tuple(empty.shape) == (1, 0)
+    with pytest.raises(NotImplementedError):
+        engine.features(audio, [0], [30000], SR, FeatureFlags())   # tonnetz on
+
+
+def test_batch_independence_and_exact_scaling(engine, flags):
+    """Size-independent properties: a segment's vector does not depend on its batch, and
+    scaling the audio by 2 scales mel power by exactly 4, shifts MFCC[0] by 10*log10(4)*sqrt(128)
+    and leaves chroma untouched (power-of-two scaling is exact in binary floating point)."""
+    from ser_amd.synth import harmonic_clips
+
+    clips = harmonic_clips(99, 6, 48000) * np.float32(0.25)
+    audio = clips.reshape(-1)
+    offs = [i * 48000 for i in range(6)]
+    lens = [48000] * 6
+    batch, _ = gpu_rows(engine, flags, audio, offs, lens)
+    for i in (0, 3, 5):
+        alone, _ = gpu_rows(engine, flags, clips[i], [0], [48000])
+        np.testing.assert_array_equal(alone[0], batch[i])
+    doubled, _ = gpu_rows(engine, flags, audio * np.float32(2.0), offs, lens)
+    np.testing.assert_array_equal(doubled[:, MEL], 4.0 * batch[:, MEL])
+    np.testing.assert_array_equal(doubled[:, CHROMA], batch[:, CHROMA])
+    np.testing.assert_allclose(doubled[:, 0] - batch[:, 0], 10.0 * np.log10(4.0) * np.sqrt(128.0), rtol=1e-5)
+    np.testing.assert_allclose(doubled[:, 1:40], batch[:, 1:40], atol=2e-3)
+
+
+def test_native_error_reporting(engine, flags):
+    from ser_amd._native import SerhipError
+
+    x = np.zeros(5000, np.float32)
+    with pytest.raises(SerhipError, match="outside the audio buffer"):
+        engine.features(x, [4000], [2000], SR, flags)
+    with pytest.raises(SerhipError, match="empty"):
+        engine.features(x, [0], [0], SR, flags)
+
+
+def test_extract_feature_from_signal_contract(engine):
+    """Reference call signature, validation order and messages (dsp.py:85-95)."""
+    from ser_amd import FeatureFlags, extract_feature_from_signal
+    from ser_amd.dsp import ParameterError
+
+    x = np.linspace(-1, 1, 6000, dtype=np.float32)
+    v = extract_feature_from_signal(x, SR, feature_flags=FeatureFlags(tonnetz=False))
+    assert v.dtype == np.float64 and v.shape == (187,)
+    assert extract_feature_from_signal(x, SR).shape == (187,)
+    with pytest.raises(ValueError, match="Sample rate must be a positive integer."):
+        extract_feature_from_signal(x, 0)
+    with pytest.raises(ValueError, match=r"Audio must be mono \(1D array\)."):
+        extract_feature_from_signal(np.zeros((4, 2), np.float32), SR)
+    with pytest.raises(ValueError, match="no samples"):
+        extract_feature_from_signal(np.zeros(0, np.float32), SR)
+    bad = x.copy()
+    bad[17] = np.nan
+    with pytest.raises(ValueError, match="not finite everywhere"):
+        extract_feature_from_signal(bad, SR)
+    with pytest.raises(ParameterError, match="exceeds Nyquist"):
+        extract_feature_from_signal(x, 8000, feature_flags=FeatureFlags(tonnetz=False))
+    assert extract_feature_from_signal(x, SR, feature_flags=FeatureFlags(False, False, False, False, False)).shape == (0,)
+
+
+def test_pooling_kernels_bit_exact(engine):
+    """mean_std_pool / HandcraftedBackend.pool on the GPU equal numpy bit for bit."""
+    from oracle import ser_fast_path as ofp
+    from ser_amd import EncodedSequence, HandcraftedBackend, PoolingWindow, mean_std_pool, temporal_pooling_windows
+
+    rng = np.random.default_rng(3)
+    emb = (rng.standard_normal((57, 187)) * 30).astype(np.float32)
+    starts = np.arange(57, dtype=np.float64)
+    ends = np.minimum(starts + 3.0, 59.0)
+    enc = EncodedSequence(emb, starts, ends, "handcrafted")
+    wins = temporal_pooling_windows(enc, window_size_seconds=10.0, window_stride_seconds=5.0)
+    want_w = ofp.temporal_pooling_windows(starts, ends, window_size_seconds=10.0, window_stride_seconds=5.0)
+    assert [(w.start_seconds, w.end_seconds) for w in wins] == want_w
+    got = mean_std_pool(enc, wins)
+    want = ofp.mean_std_pool(emb, starts, ends, want_w)
+    assert got.dtype == np.float64 and got.shape == (len(wins), 374)
+    np.testing.assert_array_equal(got, want)
+    got_mean = HandcraftedBackend().pool(enc, wins)
+    np.testing.assert_array_equal(got_mean, ofp.mean_pool(emb, starts, ends, want_w))
+    # reference known answers (tests/suites/unit/repr/test_pooling.py:12-45, test_handcrafted_backend.py:66-91)
+    small = EncodedSequence(np.asarray([[1, 2], [3, 4], [5, 6]], np.float32), np.asarray([0.0, 1.0, 2.0]),
+                            np.asarray([1.0, 2.0, 3.0]), "hf_xlsr")
+    np.testing.assert_allclose(
+        mean_std_pool(small, [PoolingWindow(0.0, 2.0), PoolingWindow(1.0, 3.0)]),
+        [[2.0, 3.0, 1.0, 1.0], [4.0, 5.0, 1.0, 1.0]])
+    assert mean_std_pool(small, []).shape == (0, 4)
+    with pytest.raises(ValueError, match="outside encoded sequence range"):
+        mean_std_pool(small, [PoolingWindow(0.0, 4.0)])
+
+
+def test_config4_long_form_reduced_and_properties(engine, flags):
+    """Config 4 (timeline sliding windows + per-segment pooling): a 150 s recording checked
+    window-by-window against the oracle on a sample, every window against a standalone
+    GPU call (no copies: windows are descriptors into one buffer), then mean/std pooling."""
+    from oracle import ser_fast_path as ofp
+    from ser_amd import HandcraftedBackend, mean_std_pool, temporal_pooling_windows
+    from ser_amd.synth import harmonic_clip
+
+    rng = np.random.default_rng(4321)
+    audio = np.concatenate([harmonic_clip(rng, 5 * SR, SR) for _ in range(30)])
+    audio = (audio / np.abs(audio).max()).astype(np.float32)
+    backend = HandcraftedBackend(feature_flags=flags)
+    enc = backend.encode_sequence(audio, SR)
+    assert enc.embeddings.shape == (150, 187)
+    bounds = ofp.window_bounds(audio.size, SR, 3, 1)
+    for i in (0, 1, 73, 147, 148, 149):
+        s, e = bounds[i]
+        want = ofp.extract_feature_from_signal(audio[s:e], SR)
+        assert_features_close(enc.embeddings[i], want)
+        alone, _ = gpu_rows(engine, flags, audio[s:e], [0], [e - s])
+        np.testing.assert_array_equal(alone[0].astype(np.float32), enc.embeddings[i])
+    wins = temporal_pooling_windows(enc, window_size_seconds=10.0, window_stride_seconds=5.0)
+    pooled = mean_std_pool(enc, wins)
+    want_w = ofp.temporal_pooling_windows(enc.frame_start_seconds, enc.frame_end_seconds,
+                                          window_size_seconds=10.0, window_stride_seconds=5.0)
+    np.testing.assert_array_equal(
+        pooled, ofp.mean_std_pool(enc.embeddings, enc.frame_start_seconds, enc.frame_end_seconds, want_w))
+
+
+def test_config4_full_hour_properties(engine, flags):
+    """Config 4 at full size (1 h @16 kHz, 3600 windows): size-independent properties only."""
+    import torch
+
+    from ser_amd.synth import harmonic_clips_torch
+
+    dev = engine.device
+    audio = harmonic_clips_torch(4321, 720, 5 * SR, dev).reshape(-1)       # 57.6 M samples
+    n = int(audio.numel())
+    starts = np.arange(0, n, SR, dtype=np.int64)
+    lens = np.minimum(starts + 3 * SR, n) - starts
+    out = engine.features(audio, starts, lens, SR, flags)
+    assert tuple(out.shape) == (3600, 187) and bool(torch.isfinite(out).all())
+    # any window recomputed alone from a copy of its samples is bit-identical
+    for i in (0, 1799, 3598, 3599):
+        seg = audio[starts[i] : starts[i] + lens[i]].clone()
+        alone = engine.features(seg, [0], [int(lens[i])], SR, flags)
+        assert torch.equal(alone[0], out[i])
+    host = out.cpu().numpy()
+    assert not host[:, 180:].any()
+    assert np.all(np.abs(host[:, CHROMA]).max(axis=1) <= 1.0 + 1e-6)
+    assert np.all(host[:, MEL] >= 0.0)
+
+
+def test_config3_full_shard_properties(engine, flags):
+    """Config 3 at one GPU's full shard (12 500 clips): duplicated clips give duplicated rows,
+    every row is finite, chunking does not change results."""
+    import torch
+
+    from ser_amd.synth import harmonic_clips_torch
+
+    base = harmonic_clips_torch(1234, 500, 48000, engine.device)
+    audio = base.repeat(25, 1).reshape(-1)                                   # 12 500 clips
+    offs = np.arange(12500, dtype=np.int64) * 48000
+    out = engine.features(audio, offs, np.full(12500, 48000), SR, flags)
+    assert tuple(out.shape) == (12500, 187) and bool(torch.isfinite(out).all())
+    first = out[:500]
+    for rep in (1, 7, 24):
+        assert torch.equal(out[rep * 500 : (rep + 1) * 500], first)
+    small = engine.features(base.reshape(-1), offs[:500], np.full(500, 48000), SR, flags)
+    assert torch.equal(small, first)
+
+
+def test_classifier_label_parity(engine, flags):
+    """Same sklearn artifact, GPU features vs oracle features: identical labels, proba within 1e-4
+    (reference classifier: StandardScaler + MLPClassifier, training_support.py:87-106)."""
+    from sklearn.neural_network import MLPClassifier
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+
+    from oracle import ser_fast_path as ofp
+    from ser_amd import HandcraftedBackend
+    from ser_amd.audio_io import prepare_audio_buffer
+    from ser_amd.synth import ravdess_sine_clip
+
+    clips, labels = [], []
+    for actor in (1, 2, 3):
+        for emo in range(1, 9):
+            clips.append(prepare_audio_buffer(ravdess_sine_clip(actor, emo)))
+            labels.append(f"emo{emo}")
+    x_ref = np.asarray([ofp.extract_vector(c, SR) for c in clips])
+    x_gpu = HandcraftedBackend(feature_flags=flags).extract_vectors(clips, SR)
+    model = Pipeline([
+        ("scaler", StandardScaler()),
+        ("classifier", MLPClassifier(alpha=0.01, batch_size=256, epsilon=1e-08, hidden_layer_sizes=(300,),
+                                     learning_rate="adaptive", max_iter=500, random_state=42)),
+    ])
+    model.fit(x_ref, labels)
+    assert list(model.predict(x_gpu)) == list(model.predict(x_ref))
+    np.testing.assert_allclose(model.predict_proba(x_gpu), model.predict_proba(x_ref), atol=1e-4)
+
+
+def test_config5_whisper_logmel(engine):
+    """Config 5: whisper-style 80-bin log-mel vs the oracle (atol 1e-5) and vs HF's extractor."""
+    from oracle.whisper_logmel import log_mel_spectrogram as oracle_logmel
+    from ser_amd import log_mel_spectrogram
+    from ser_amd.synth import harmonic_clips
+
+    clips = harmonic_clips(99, 3, 16000 * 5)
+    got = log_mel_spectrogram(clips, 80)
+    assert got.shape == (3, 80, 500) and got.dtype == np.float32
+    for i in range(3):
+        np.testing.assert_allclose(got[i], oracle_logmel(clips[i], 80), atol=1e-5)
+    one = log_mel_spectrogram(clips[1], 128)
+    np.testing.assert_allclose(one, oracle_logmel(clips[1], 128), atol=1e-5)
+    odd = log_mel_spectrogram(clips[2][:12345], 80)
+    np.testing.assert_allclose(odd, oracle_logmel(clips[2][:12345], 80), atol=1e-5)
+    from transformers.models.whisper.feature_extraction_whisper import WhisperFeatureExtractor
+
+    hf = WhisperFeatureExtractor()._np_extract_fbank_features(clips[:1].astype(np.float64), "cpu")
+    np.testing.assert_allclose(got[0], hf[0][:, :500], atol=1e-5)
