@@ -1,0 +1,65 @@
+"""The N > 1 path on CPU: contiguous sharding by utterance and the single all-gather that
+assembles the feature matrix, with the gloo backend and world_size 2 (uneven shards included)."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from ser_amd.distributed import shard_bounds, shard_range
+
+
+def test_shard_bounds():
+    assert shard_bounds(100_000, 8).tolist() == [0, 12500, 25000, 37500, 50000, 62500, 75000, 87500, 100000]
+    assert shard_bounds(10, 4).tolist() == [0, 3, 6, 9, 10]
+    assert shard_bounds(3, 4).tolist() == [0, 1, 2, 3, 3]
+    assert shard_bounds(0, 2).tolist() == [0, 0, 0]
+    assert shard_range(3600, 1, 2) == (1800, 3600)
+    covered = [shard_range(17, r, 5) for r in range(5)]
+    assert covered[0][0] == 0 and covered[-1][1] == 17
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    with pytest.raises(ValueError):
+        shard_bounds(5, 0)
+
+
+def _worker(rank, world, port, n_total, dim, result_dir):
+    import torch
+    import torch.distributed as dist
+
+    from ser_amd.distributed import all_gather_rows, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = torch.arange(n_total * dim, dtype=torch.float32).reshape(n_total, dim)
+    lo, hi = shard_range(n_total, rank, world)
+    gathered = all_gather_rows(full[lo:hi].clone(), n_total)
+    ok = torch.equal(gathered, full)
+    with open(os.path.join(result_dir, f"rank{rank}.txt"), "w") as f:
+        f.write("ok" if ok else "mismatch")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 7, 1])
+def test_all_gather_rows_gloo_world2(tmp_path, n_total):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, n_total, 5, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert (tmp_path / f"rank{r}.txt").read_text() == "ok"
+
+
+def test_all_gather_single_process_passthrough():
+    import torch
+
+    from ser_amd.distributed import all_gather_rows
+
+    x = torch.ones((4, 3))
+    assert all_gather_rows(x, 4) is x
+    with pytest.raises(ValueError):
+        all_gather_rows(x, 5)
+    assert np.asarray(x).shape == (4, 3)

@@ -361,3 +361,32 @@ def test_config5_whisper_logmel(engine):
 
     hf = WhisperFeatureExtractor()._np_extract_fbank_features(clips[:1].astype(np.float64), "cpu")
     np.testing.assert_allclose(got[0], hf[0][:, :500], atol=1e-5)
+
+
+def test_against_committed_golden_vectors(engine, flags):
+    """GPU path vs tests/golden/fast_path_golden.npz (no oracle run needed on the GPU box)."""
+    from pathlib import Path
+
+    from ser_amd import HandcraftedBackend, log_mel_spectrogram
+    from ser_amd.audio_io import prepare_audio_buffer
+    from ser_amd.synth import harmonic_clips, ravdess_sine_clip, sample_wav_like
+
+    g = np.load(Path(__file__).parent / "golden" / "fast_path_golden.npz")
+    clips = harmonic_clips(1234, 6, 48000)
+    got, tun = gpu_rows(engine, flags, clips.reshape(-1), [i * 48000 for i in range(6)], [48000] * 6)
+    np.testing.assert_allclose(tun, g["clips_tuning"], atol=1e-6)
+    assert_features_close(got, g["clips_features"])
+    backend = HandcraftedBackend(feature_flags=flags)
+    enc = backend.encode_sequence(sample_wav_like(), SR)
+    assert_features_close(enc.embeddings, g["sample_embeddings"])
+    np.testing.assert_array_equal(enc.frame_start_seconds, g["sample_starts"])
+    np.testing.assert_array_equal(enc.frame_end_seconds, g["sample_ends"])
+    rav = [prepare_audio_buffer(ravdess_sine_clip(a, e)) for a in (1, 2) for e in range(1, 9)]
+    assert_features_close(backend.extract_vectors(rav, SR), g["ravdess_features"])
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(40000).astype(np.float32)
+    x /= np.abs(x).max()
+    got, tun = gpu_rows(engine, flags, x, g["ragged_offsets"], g["ragged_lengths"])
+    np.testing.assert_allclose(tun, g["ragged_tuning"], atol=1e-6)
+    assert_features_close(got, g["ragged_features"])
+    np.testing.assert_allclose(log_mel_spectrogram(harmonic_clips(99, 2, 32000), 80), g["whisper_logmel80"], atol=1e-5)

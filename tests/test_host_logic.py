@@ -1,0 +1,206 @@
+"""Host-side contract tests (no GPU): the reference's own known answers for the boundary
+types, windowing, pooling windows, audio preparation and error strings."""
+
+import wave
+
+import numpy as np
+import pytest
+
+import ser_amd
+from ser_amd import (
+    AudioReadConfig,
+    EncodedSequence,
+    FeatureBackend,
+    FeatureFlags,
+    PoolingWindow,
+    VectorFeatureBackend,
+    overlap_frame_mask,
+)
+from ser_amd.audio_io import AudioDecodeError, AudioIntegrityError, prepare_audio_buffer, read_audio_file
+from ser_amd.handcrafted import HandcraftedBackend, sliding_window_bounds
+from ser_amd.pool import temporal_pooling_windows, window_frame_ranges
+
+
+def seq(rows, starts, ends, backend_id="handcrafted"):
+    return EncodedSequence(np.asarray(rows, np.float32), np.asarray(starts, np.float64),
+                           np.asarray(ends, np.float64), backend_id)
+
+
+def test_feature_dims_and_backend_identity():
+    # tests/suites/unit/repr/test_handcrafted_backend.py:13-24, integration/test_fast_inference.py:27-46
+    assert FeatureFlags().width() == 193
+    assert FeatureFlags(tonnetz=False).width() == 187
+    b = HandcraftedBackend(feature_flags=FeatureFlags())
+    assert b.backend_id == "handcrafted" and b.feature_dim == 193
+    assert HandcraftedBackend().feature_dim == 187          # accelerated default: tonnetz off
+    assert HandcraftedBackend(feature_flags=FeatureFlags(False, True, False, True, False)).feature_dim == 19
+    assert isinstance(b, FeatureBackend) and isinstance(b, VectorFeatureBackend)
+    assert FeatureFlags(tonnetz=False).native_bits() == 15
+    assert AudioReadConfig() == AudioReadConfig(max_retries=3, retry_delay_seconds=1.0)
+
+
+def test_backend_constructor_validation():
+    # test_handcrafted_backend.py:112-117
+    with pytest.raises(ValueError, match="frame_size_seconds"):
+        HandcraftedBackend(frame_size_seconds=0)
+    with pytest.raises(ValueError, match="frame_stride_seconds"):
+        HandcraftedBackend(frame_stride_seconds=0)
+
+
+def test_sliding_window_bounds_known_answer():
+    # 10 samples @ 2 Hz, size 2 s, stride 1 s -> sizes [4,4,4,4,2] (test_feature_extractor.py:79-163)
+    starts, ends = sliding_window_bounds(10, 2, 2, 1)
+    assert starts.tolist() == [0, 2, 4, 6, 8] and ends.tolist() == [4, 6, 8, 10, 10]
+    assert (starts / 2.0).tolist() == [0, 1, 2, 3, 4] and (ends / 2.0).tolist() == [2, 3, 4, 5, 5]
+    s, e = sliding_window_bounds(69937, 16000, 3, 1)
+    assert (e - s).tolist() == [48000, 48000, 37937, 21937, 5937]
+    s, e = sliding_window_bounds(57_600_000, 16000, 3, 1)
+    assert s.size == 3600 and (e - s)[-2:].tolist() == [32000, 16000]
+
+
+def test_encoded_sequence_validation_messages():
+    # tests/suites/unit/repr/test_backend_contract.py:95-114
+    with pytest.raises(ValueError, match="frame_end_seconds length"):
+        seq([[1, 2], [3, 4]], [0.0, 1.0], [1.0])
+    with pytest.raises(ValueError, match="end_seconds > start_seconds"):
+        seq([[1, 2]], [1.0], [1.0])
+    with pytest.raises(ValueError, match="non-empty string"):
+        seq([[1, 2]], [0.0], [1.0], backend_id="")
+    with pytest.raises(ValueError, match="must be 2D"):
+        seq([1, 2], [0.0], [1.0])
+    with pytest.raises(ValueError, match="non-finite"):
+        seq([[np.nan, 2]], [0.0], [1.0])
+    with pytest.raises(ValueError, match="non-decreasing"):
+        seq([[1, 2], [3, 4]], [1.0, 0.0], [2.0, 3.0])
+    with pytest.raises(ValueError, match="at least one frame"):
+        seq(np.zeros((0, 2)), [], [])
+
+
+def test_pooling_window_validation():
+    with pytest.raises(ValueError, match="finite"):
+        PoolingWindow(0.0, float("inf"))
+    with pytest.raises(ValueError, match="non-negative"):
+        PoolingWindow(-0.1, 1.0)
+    with pytest.raises(ValueError, match="greater than start_seconds"):
+        PoolingWindow(1.0, 1.0)
+
+
+def test_overlap_mask_and_ranges():
+    # test_backend_contract.py:142-165, test_handcrafted_backend.py:66-91
+    enc = seq([[0, 3], [2, 5], [4, 7], [6, 9], [8, 9]], [0, 1, 2, 3, 4], [2, 3, 4, 5, 5])
+    assert overlap_frame_mask(enc, PoolingWindow(0.0, 1.0)).tolist() == [True, False, False, False, False]
+    assert overlap_frame_mask(enc, PoolingWindow(2.0, 4.0)).tolist() == [False, True, True, True, False]
+    with pytest.raises(ValueError, match="outside encoded sequence range"):
+        overlap_frame_mask(enc, PoolingWindow(0.0, 6.0))
+    gap = seq([[1], [2]], [0.0, 2.0], [1.0, 3.0])
+    with pytest.raises(ValueError, match="does not overlap any encoded frames"):
+        overlap_frame_mask(gap, PoolingWindow(1.2, 1.8))
+    lo, hi = window_frame_ranges(enc, [PoolingWindow(0.0, 1.0), PoolingWindow(2.0, 4.0)])
+    assert lo.tolist() == [0, 1] and hi.tolist() == [1, 4]
+    # mask semantics equal the reference's boolean expression on random monotone timelines
+    rng = np.random.default_rng(0)
+    starts = np.sort(rng.random(40) * 10)
+    ends = starts + 0.5 + rng.random(40)
+    ends = np.maximum.accumulate(ends)
+    enc2 = seq(np.zeros((40, 1)), starts, ends)
+    for _ in range(50):
+        a = rng.uniform(starts[0], ends[-1] - 0.01)
+        b = rng.uniform(a + 0.001, ends[-1])
+        ref = np.logical_and(ends > a, starts < b)
+        if ref.any():
+            np.testing.assert_array_equal(overlap_frame_mask(enc2, PoolingWindow(a, b)), ref)
+
+
+def test_temporal_pooling_windows_known_answers():
+    # tests/suites/unit/repr/test_pooling.py:78-138
+    enc = seq(np.zeros((4, 2)), [0, 1, 2, 3], [1, 2, 3, 4])
+    w = temporal_pooling_windows(enc, window_size_seconds=2.0, window_stride_seconds=1.5)
+    assert [(x.start_seconds, x.end_seconds) for x in w] == [(0.0, 2.0), (1.5, 3.5), (2.0, 4.0)]
+    short = seq(np.zeros((1, 2)), [0.0], [1.0])
+    w = temporal_pooling_windows(short, window_size_seconds=3.0, window_stride_seconds=1.0)
+    assert [(x.start_seconds, x.end_seconds) for x in w] == [(0.0, 1.0)]
+    with pytest.raises(ValueError, match="window_size_seconds"):
+        temporal_pooling_windows(enc, window_size_seconds=0.0, window_stride_seconds=1.0)
+    with pytest.raises(ValueError, match="window_stride_seconds"):
+        temporal_pooling_windows(enc, window_size_seconds=1.0, window_stride_seconds=-0.1)
+    hour = seq(np.zeros((3600, 1)), np.arange(3600.0), np.minimum(np.arange(3600.0) + 3, 3600.0))
+    assert len(temporal_pooling_windows(hour, window_size_seconds=10.0, window_stride_seconds=5.0)) == 719
+
+
+def test_prepare_audio_buffer_known_answers():
+    # tests/suites/unit/utils/test_audio_utils.py:14-27
+    out = prepare_audio_buffer(np.asarray([[0.2, 0.0], [0.4, 0.0]], np.float32))
+    assert out.dtype == np.float32
+    np.testing.assert_allclose(out, [0.5, 1.0])
+    with pytest.raises(OSError, match="contains no samples"):
+        prepare_audio_buffer(np.zeros(0, np.float32))
+    np.testing.assert_array_equal(prepare_audio_buffer(np.asarray([np.nan, np.inf, -2.0, 1.0], np.float32)),
+                                  [0.0, 0.0, -1.0, 0.5])
+    assert not prepare_audio_buffer(np.zeros(5, np.float32)).any()
+    src = np.asarray([0.5, -0.25], np.float32)
+    prepare_audio_buffer(src)
+    np.testing.assert_array_equal(src, [0.5, -0.25])          # inputs are never mutated
+
+
+def test_read_audio_file(tmp_path):
+    from ser_amd.synth import ravdess_sine_clip, write_wav_pcm16
+
+    clip = ravdess_sine_clip(1, 3)
+    path = tmp_path / "Actor_01" / "03-01-03-01-01-01-01.wav"
+    path.parent.mkdir()
+    write_wav_pcm16(path, np.rint(clip * 32768).astype(np.int16), 16000)
+    audio, sr = read_audio_file(str(path))
+    assert sr == 16000 and audio.dtype == np.float32 and audio.shape == (24000,)
+    np.testing.assert_array_equal(audio, prepare_audio_buffer(clip))
+    seg, _ = read_audio_file(str(path), start_seconds=0.5, duration_seconds=0.25)
+    assert seg.shape == (4000,)
+    stereo = tmp_path / "stereo.wav"
+    with wave.open(str(stereo), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(8000)
+        w.writeframes(np.asarray([[1000, 3000], [-2000, -2000]], "<i2").tobytes())
+    a2, sr2 = read_audio_file(str(stereo))
+    assert sr2 == 8000
+    np.testing.assert_allclose(a2, [1.0, -1.0])
+    with pytest.raises(FileNotFoundError, match="Audio file not found"):
+        read_audio_file(str(tmp_path / "missing.wav"))
+    with pytest.raises(ValueError, match="start_seconds"):
+        read_audio_file(str(path), start_seconds=-1.0)
+    with pytest.raises(ValueError, match="duration_seconds"):
+        read_audio_file(str(path), duration_seconds=0.0)
+    lfs = tmp_path / "pointer.wav"
+    lfs.write_bytes(b"version https://git-lfs.github.com/spec/v1\noid sha256:0\nsize 1\n")
+    with pytest.raises(AudioIntegrityError, match="Git LFS pointer"):
+        read_audio_file(str(lfs))
+    junk = tmp_path / "junk.wav"
+    junk.write_bytes(b"not audio at all")
+    with pytest.raises(AudioDecodeError, match="Error reading"):
+        read_audio_file(str(junk), audio_read_config=AudioReadConfig(max_retries=2, retry_delay_seconds=0.0))
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a GPU the product path must raise; it never routes through the CPU oracle."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    x = np.linspace(-1, 1, 4000, dtype=np.float32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ser_amd.extract_feature_from_signal(x, 16000)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HandcraftedBackend().encode_sequence(x, 16000)
+    # input validation still happens first, with the reference's messages
+    with pytest.raises(ValueError, match="no samples"):
+        ser_amd.extract_feature_from_signal(np.zeros(0, np.float32), 16000)
+    with pytest.raises(ValueError, match="at least one sample"):
+        HandcraftedBackend().encode_sequence(np.zeros(0, np.float32), 16000)
+
+
+def test_product_never_imports_the_oracle():
+    from pathlib import Path
+
+    root = Path(ser_amd.__file__).resolve().parent
+    for path in list(root.rglob("*.py")) + list(root.rglob("*.hpp")) + list(root.rglob("*.hip")):
+        text = path.read_text()
+        assert "import oracle" not in text and "from oracle" not in text, path
