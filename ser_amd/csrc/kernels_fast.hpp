@@ -18,10 +18,15 @@
 
 namespace serhip {
 
-constexpr int kWaves = 4;              // waves per workgroup in k_stft_frames
-constexpr int kFramesPerBlock = 16;    // STFT frames per workgroup
-constexpr int kBufC = 1088;            // complex slots of one wave's LDS buffer (16 rows x stride 68)
-constexpr int kMelWCap = 2304;         // capacity of the sparse mel weight stream
+#ifndef SERHIP_K1_WAVES
+#define SERHIP_K1_WAVES 12
+#endif
+// k_stft_frames runs ONE workgroup per CU: its waves share the 30 KB of twiddle/window/mel tables in
+// LDS and each owns an 8.5 KB transpose buffer; 12 waves = 3 per SIMD at <= 168 VGPRs.
+constexpr int kWaves = SERHIP_K1_WAVES; // waves per workgroup in k_stft_frames
+constexpr int kFramesPerBlock = 8 * kWaves;   // STFT frames per workgroup
+constexpr int kBufC = 1152;            // complex slots of one wave's LDS buffer (transposes need 16 x 68; |X|^2 + |X| + peaks 2304 floats)
+constexpr int kMelWCap = 3072;         // capacity of the 4-aligned sparse mel weight stream
 constexpr int kPeakLdsCap = 3072;      // peaks staged in LDS by k_segment_finish
 constexpr int kChromaTableStride = 1025 * 12 + 4;  // floats per tuning in the chroma table ([k][12], 16-B rows)
 
@@ -43,13 +48,14 @@ struct PlanTables {
     const v2f* twB;       // [16][4]   W_64^(m2*j1)
     const v2f* twU;       // [8][64]   W_2048^(lane+64r)
     const v2f* win;       // [16][64]  Hann pairs (w[128n1+2l], w[128n1+2l+1])
-    const float* mel_w;   // sparse mel weights, filter-major
-    const int4* mel_rng;  // [128] (first bin, count, offset into mel_w, 0)
+    const float* mel_w;   // sparse mel weights, filter-major, each filter zero-padded to 4-aligned bins;
+                          // floats 0..3 are a shared zero group
+    const int4* mel_rng;  // [128] (first bin & ~3, groups of 4 taps, offset into mel_w, 0)
+    int mel_nnz;
     const float* chroma;  // [101][kChromaTableStride]: per tuning [bin][12]
     const float* dct;     // [40][128]
     const double* edges;  // [101] histogram edges np.linspace(-0.5, 0.5, 101)
     const double* mel_f;  // [130] mel band edges in Hz (generic path)
-    int mel_nnz;
     int kmin, kmax;       // piptrack bin range (inclusive) for n_fft 2048
     int sample_rate;
     unsigned flags;
@@ -95,6 +101,7 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 // piptrack arithmetic for one local maximum (librosa.piptrack, called from estimate_tuning
 // inside chroma_stft; dsp.py:115).  sm/s0/sp = S[i-1], S[i], S[i+1] (f32 magnitudes).
 // The parabolic shift is a double division of float32 sums, as numba evaluates the stencil.
+template <bool kPow2>
 __device__ __forceinline__ v2f piptrack_peak(float sm, float s0, float sp, int i, double bin_hz_num,
                                              double n_fft_d) {
 #pragma clang fp contract(off)  // numpy / numba round every product and sum separately
@@ -106,7 +113,9 @@ __device__ __forceinline__ v2f piptrack_peak(float sm, float s0, float sp, int i
     if (!(fabs(b) >= fabs(a))) shift = static_cast<float>(-b / a);
     const float avg = dif / 2.0f;                 // np.gradient interior point, f32
     const float dskew = __fmul_rn(0.5f * avg, shift);   // separately rounded, as numpy does
-    const double pitch = (static_cast<double>(i) + static_cast<double>(shift)) * bin_hz_num / n_fft_d;
+    // (i + shift) * sr / n_fft; for a power-of-two n_fft the division is an exact scaling
+    const double scaled = (static_cast<double>(i) + static_cast<double>(shift)) * bin_hz_num;
+    const double pitch = kPow2 ? scaled * (1.0 / n_fft_d) : scaled / n_fft_d;
     return v2f{static_cast<float>(pitch), __fadd_rn(s0, dskew)};
 }
 
@@ -120,8 +129,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     __shared__ v2f s_twU[8 * 64];
     __shared__ v2f s_win[16 * 64];
     __shared__ v2f s_twB[16 * 4];
-    __shared__ float s_melw[kMelWCap];
-    __shared__ v2f s_buf[kWaves][kBufC];
+    __shared__ __attribute__((aligned(16))) float s_melw[kMelWCap];
+    __shared__ __attribute__((aligned(16))) v2f s_buf[kWaves][kBufC];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -141,8 +150,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
 
     v2f* buf = s_buf[wave];
     float* fbuf = reinterpret_cast<float*>(buf);
-    float* sP = fbuf;            // power, bins 0..1024
-    float* sM = fbuf + 1032;     // magnitude, bins 0..1024
+    float* sP = fbuf;            // |X|^2, bins 0..1024 (+3 zero pads), natural order
+    float* sM = fbuf + 1028;     // |X|,   bins 0..1024
 
     const float* seg_audio = audio + sd.offset;
     const bool aligned = ((reinterpret_cast<uintptr_t>(seg_audio) & 7u) == 0);
@@ -158,18 +167,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     const bool want_mel = (tb.flags & 5u) != 0;
 
     const int t_end = min(t_begin + kFramesPerBlock, sd.n_stft);
-    for (int t = t_begin + wave; t < t_end; t += kWaves) {
-        // ---- framing + window: frame t covers segment samples [t*512 - 1024, t*512 + 1024)
+    // frame t covers segment samples [t*512 - 1024, t*512 + 1024); lane l holds the 16 sample
+    // pairs 128*n1 + 2*l.  Out-of-range samples are the zero padding of librosa.stft(center=True).
+    auto load_frame = [&](int t, v2f (&dst)[16]) {
         const long long fs = static_cast<long long>(t) * kHop - kNfft / 2;
-        v2f v[16];
         if (fs >= 0 && fs + kNfft <= sd.len) {
             const float* p = seg_audio + fs + 2 * lane;
             if (aligned) {
 #pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) v[n1] = *reinterpret_cast<const v2f*>(p + 128 * n1);
+                for (int n1 = 0; n1 < 16; ++n1) dst[n1] = *reinterpret_cast<const v2f*>(p + 128 * n1);
             } else {
 #pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) v[n1] = v2f{p[128 * n1], p[128 * n1 + 1]};
+                for (int n1 = 0; n1 < 16; ++n1) dst[n1] = v2f{p[128 * n1], p[128 * n1 + 1]};
             }
         } else {
 #pragma unroll
@@ -177,9 +186,17 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
                 const long long s = fs + 128 * n1 + 2 * lane;
                 const float a = (s >= 0 && s < sd.len) ? seg_audio[s] : 0.0f;
                 const float b = (s + 1 >= 0 && s + 1 < sd.len) ? seg_audio[s + 1] : 0.0f;
-                v[n1] = v2f{a, b};
+                dst[n1] = v2f{a, b};
             }
         }
+    };
+    v2f vnext[16];
+    if (t_begin + wave < t_end) load_frame(t_begin + wave, vnext);
+    for (int t = t_begin + wave; t < t_end; t += kWaves) {
+        v2f v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = vnext[n1];
+        if (t + kWaves < t_end) load_frame(t + kWaves, vnext);   // prefetch: latency hides behind this frame's FFT
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = v[n1] * s_win[n1 * 64 + lane];
 
@@ -223,13 +240,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             const v2f t2 = cmul(o2, s_twU[r * 64 + lane]);
             const v2f xlo = 0.5f * (e2 + t2);
             const v2f xhi = 0.5f * (e2 - t2);
-            mlo[r] = sqrtf(xlo.x * xlo.x + xlo.y * xlo.y);
-            mhi[r] = sqrtf(xhi.x * xhi.x + xhi.y * xhi.y);
+            mlo[r] = __builtin_amdgcn_sqrtf(xlo.x * xlo.x + xlo.y * xlo.y);   // v_sqrt_f32, <= 1 ulp
+            mhi[r] = __builtin_amdgcn_sqrtf(xhi.x * xhi.x + xhi.y * xhi.y);
         }
         float m512 = 0.0f;
         if (lane == 0) {
             const v2f z = buf[512 + 8];
-            m512 = sqrtf(z.x * z.x + z.y * z.y);
+            m512 = __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);
         }
         wave_lds_sync();  // every lane has read Z before the buffer is reused
 
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             const int k = lane + 64 * r;
             sM[k] = mlo[r];
             sM[1024 - k] = mhi[r];
-            sP[k] = mlo[r] * mlo[r];
+            sP[k] = mlo[r] * mlo[r];            // np.abs(D)**2: the square of the rounded magnitude
             sP[1024 - k] = mhi[r] * mhi[r];
             cmax = fmaxf(cmax, fmaxf(mlo[r], mhi[r]));
         }
@@ -248,61 +265,77 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             sM[512] = m512;
             sP[512] = m512 * m512;
         }
-        if (want_chroma) {
-            float* mrow = sc.mags + row * kBinStride;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int k = lane + 64 * r;
-                mrow[k] = mlo[r];
-                mrow[1024 - k] = mhi[r];
-            }
-            if (lane == 0) mrow[512] = m512;
-        }
+        if (lane < 3) sP[1025 + lane] = 0.0f;   // the 4-wide mel reads may touch bins 1025..1027
         wave_lds_sync();
 
-        // ---- sparse Slaney mel projection: lane owns filters `lane` and `127 - lane`
+        // ---- magnitudes for the chroma pass: lane l takes the 16 consecutive bins 16l..16l+15 from
+        // LDS (4 x ds_read_b128) and stores them with 4 x 16-byte stores (4 KB contiguous per wave)
+        if (want_chroma) {
+            const float4* mp = reinterpret_cast<const float4*>(sM + 16 * lane);
+            float4* mrow = reinterpret_cast<float4*>(sc.mags + row * kBinStride + 16 * lane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mrow[u] = mp[u];
+            if (lane == 0) sc.mags[row * kBinStride + 1024] = mhi[0];
+        }
+
+        // ---- sparse Slaney mel projection: lane owns filters `lane` and `127 - lane`.  A filter's
+        // taps are consecutive bins, so weights and powers are read four at a time (ds_read_b128)
+        // from 4-aligned starts; lanes whose filter is exhausted read a shared zero group.
         if (want_mel) {
             float acc0 = 0.0f, acc1 = 0.0f;
-            const int n0 = rng0.y, n1c = rng1.y;
-            const int nmax = max(n0, n1c);
-            for (int j = 0; j < nmax; ++j) {
-                if (j < n0) acc0 = fmaf(s_melw[rng0.z + j], sP[rng0.x + j], acc0);
-                if (j < n1c) acc1 = fmaf(s_melw[rng1.z + j], sP[rng1.x + j], acc1);
+            const int nmax4 = max(rng0.y, rng1.y);
+#pragma unroll 2
+            for (int g = 0; g < nmax4; ++g) {
+                const bool in0 = g < rng0.y, in1 = g < rng1.y;
+                const float4 w0 = *reinterpret_cast<const float4*>(s_melw + (in0 ? rng0.z + 4 * g : 0));
+                const float4 p0 = *reinterpret_cast<const float4*>(sP + (in0 ? rng0.x + 4 * g : 0));
+                const float4 w1 = *reinterpret_cast<const float4*>(s_melw + (in1 ? rng1.z + 4 * g : 0));
+                const float4 p1 = *reinterpret_cast<const float4*>(sP + (in1 ? rng1.x + 4 * g : 0));
+                acc0 = fmaf(w0.x, p0.x, acc0);
+                acc0 = fmaf(w0.y, p0.y, acc0);
+                acc0 = fmaf(w0.z, p0.z, acc0);
+                acc0 = fmaf(w0.w, p0.w, acc0);
+                acc1 = fmaf(w1.x, p1.x, acc1);
+                acc1 = fmaf(w1.y, p1.y, acc1);
+                acc1 = fmaf(w1.z, p1.z, acc1);
+                acc1 = fmaf(w1.w, p1.w, acc1);
             }
             float* melrow = sc.mel + (static_cast<size_t>(sd.mel_base) + t) * kMels;
             melrow[lane] = acc0;
             melrow[127 - lane] = acc1;
         }
 
-        // ---- piptrack peaks (bins kmin..kmax), threshold 0.1 * column max
+        // ---- piptrack peaks (bins kmin..kmax), threshold 0.1 * column max.  Pass 1 finds the local
+        // maxima and compacts their bin numbers into LDS; pass 2 gives each lane one peak, so the
+        // double-precision interpolation runs once per 64 peaks instead of once per bin stripe.
         if (want_chroma) {
             cmax = wave_max(cmax);
             const float ref = 0.1f * cmax;
-            v2f* prow = sc.peaks + row * sc.peak_cap;
+            int* cand = reinterpret_cast<int*>(fbuf + 2056);   // behind sP and sM
             int base = 0;
             for (int r = 0; 64 * r <= tb.kmax; ++r) {
                 const int k = lane + 64 * r;
                 bool is_peak = false;
-                float sm = 0.f, s0 = 0.f, sp = 0.f;
                 if (k >= tb.kmin && k <= tb.kmax) {
-                    sm = sM[k - 1];
-                    s0 = sM[k];
-                    sp = sM[k + 1];
+                    const float sm = sM[k - 1], s0 = sM[k], sp = sM[k + 1];
                     const float tm = sm > ref ? sm : 0.0f;
                     const float t0 = s0 > ref ? s0 : 0.0f;
                     const float tp = sp > ref ? sp : 0.0f;
                     is_peak = (t0 > tm) && (t0 >= tp);
                 }
                 const unsigned long long mask = __ballot(is_peak);
-                if (is_peak) {
-                    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-                    prow[pos] = piptrack_peak(sm, s0, sp, k, sr_d, static_cast<double>(kNfft));
-                }
+                if (is_peak) cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = k;
                 base += __popcll(mask);
+            }
+            wave_lds_sync();
+            v2f* prow = sc.peaks + row * sc.peak_cap;
+            for (int i = lane; i < base; i += 64) {
+                const int k = cand[i];
+                prow[i] = piptrack_peak<true>(sM[k - 1], sM[k], sM[k + 1], k, sr_d, static_cast<double>(kNfft));
             }
             if (lane == 0) sc.peak_cnt[row] = base;
         }
-        wave_lds_sync();  // sP / sM reads done before the next frame overwrites the buffer
+        wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
     }
 }
 
@@ -579,17 +612,50 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         float v[64];
 #pragma unroll
         for (int i = 0; i < 64; ++i) v[i] = 0.0f;
-        for (int k = lane; k < nbins; k += 64) {
-            float x[4];
+        if (sd.n_fft == kNfft) {
+            // 1025 bins: two batches of 32 global loads, each issued before its FMAs
 #pragma unroll
-            for (int f = 0; f < 4; ++f) x[f] = mrow[f][k];
-            const float4* wp = reinterpret_cast<const float4*>(sh.fb + k * kChroma);
-            const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-            const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+            for (int half = 0; half < 2; ++half) {
+                float x[4][8];
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+                for (int r = 0; r < 8; ++r)
 #pragma unroll
-                for (int c = 0; c < 12; ++c) v[f * 16 + c] = fmaf(w[c], x[f], v[f * 16 + c]);
+                    for (int f = 0; f < 4; ++f) x[f][r] = mrow[f][lane + 64 * (8 * half + r)];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float4* wp = reinterpret_cast<const float4*>(sh.fb + (lane + 64 * (8 * half + r)) * kChroma);
+                    const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                    const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int c = 0; c < 12; ++c) v[f * 16 + c] = fmaf(w[c], x[f][r], v[f * 16 + c]);
+                }
+            }
+            if (lane == 0) {   // bin 1024
+                const float4* wp = reinterpret_cast<const float4*>(sh.fb + 1024 * kChroma);
+                const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const float xe = mrow[f][1024];
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) v[f * 16 + c] = fmaf(w[c], xe, v[f * 16 + c]);
+                }
+            }
+        } else {
+            for (int k = lane; k < nbins; k += 64) {
+                float x[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) x[f] = mrow[f][k];
+                const float4* wp = reinterpret_cast<const float4*>(sh.fb + k * kChroma);
+                const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) v[f * 16 + c] = fmaf(w[c], x[f], v[f * 16 + c]);
+            }
         }
         // halving butterfly: after the stage with offset o, lane keeps the half selected by (lane & o)
 #pragma unroll

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_dft_frames(const float* __restrict__ au
         const float tp = sp > ref ? sp : 0.0f;
         if ((t0 > tm) && (t0 >= tp)) {
             const int pos = atomicAdd(&s_cnt, 1);
-            prow[pos] = piptrack_peak(sm, s0, sp, k, static_cast<double>(tb.sample_rate),
+            prow[pos] = piptrack_peak<false>(sm, s0, sp, k, static_cast<double>(tb.sample_rate),
                                       static_cast<double>(n_pip));
         }
     }

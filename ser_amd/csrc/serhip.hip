@@ -77,8 +77,10 @@ void build_host_tables(int sr, HostTables& h, bool with_chroma) {
             h.win[n1 * 64 + l] = v2f{static_cast<float>(h.window[128 * n1 + 2 * l]),
                                      static_cast<float>(h.window[128 * n1 + 2 * l + 1])};
     h.mel_dense = mel_filterbank(sr, kNfft, kMels);
+    // sparse stream for k_stft_frames: floats 0..3 are a zero group; every filter starts at a
+    // 4-aligned bin and is zero-padded to whole groups of 4 taps (16-byte LDS reads)
     h.mel_rng.assign(kMels, int4{0, 0, 0, 0});
-    h.mel_w.clear();
+    h.mel_w.assign(4, 0.0f);
     for (int m = 0; m < kMels; ++m) {
         int first = -1, last = -1;
         for (int k = 0; k < kBins; ++k)
@@ -87,8 +89,11 @@ void build_host_tables(int sr, HostTables& h, bool with_chroma) {
                 last = k;
             }
         if (first >= 0) {
-            h.mel_rng[m] = int4{first, last - first + 1, static_cast<int>(h.mel_w.size()), 0};
-            for (int k = first; k <= last; ++k) h.mel_w.push_back(h.mel_dense[static_cast<size_t>(m) * kBins + k]);
+            const int start = first & ~3;
+            const int groups = (last - start + 4) / 4;
+            h.mel_rng[m] = int4{start, groups, static_cast<int>(h.mel_w.size()), 0};
+            for (int k = start; k < start + 4 * groups; ++k)
+                h.mel_w.push_back(k < kBins ? h.mel_dense[static_cast<size_t>(m) * kBins + k] : 0.0f);
         }
     }
     h.dct = dct_ortho(kMfcc, kMels);
