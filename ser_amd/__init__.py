@@ -35,6 +35,13 @@ _LAZY = {
     "read_audio_file": ("audio_io", "read_audio_file"),
     "log_mel_spectrogram": ("whisper_frontend", "log_mel_spectrogram"),
     "get_engine": ("engine", "get_engine"),
+    "load_data": ("data_loader", "load_data"),
+    "load_checked_fast_data": ("data_loader", "load_checked_fast_data"),
+    "featurize_files": ("data_loader", "featurize_files"),
+    "process_file": ("data_loader", "process_file"),
+    "LoaderSettings": ("data_loader", "LoaderSettings"),
+    "write_prepared_feature_payload": ("prepared_cache", "write_prepared_feature_payload"),
+    "read_prepared_feature_payload": ("prepared_cache", "read_prepared_feature_payload"),
 }
 
 
