@@ -143,6 +143,7 @@ def main() -> None:
     engine._ctx.profile_enable(False)
     k1_ms, k1_n = engine._ctx.profile_read(0)
     k2_ms, k2_n = engine._ctx.profile_read(1)
+    k3_ms, k3_n = engine._ctx.profile_read(3)
     assert tuple(out.shape) == (n_total, FEATURE_DIM)
     assert bool(torch.isfinite(out).all())
 
@@ -195,7 +196,8 @@ def main() -> None:
                 "traffic": traffic,
                 "launches_per_step": k1_n / max(1, args.steps),
                 "avg_launch_ms": k1_ms / max(1, k1_n),
-                "finish_kernel_ms_per_step": k2_ms / max(1, args.steps),
+                "finish_kernels_ms_per_step": k2_ms / max(1, args.steps),
+                "project_kernel_ms_per_step": k3_ms / max(1, args.steps),
                 "whole_path_frac": (value / world) * (ALGO_BYTES_PER_CLIP / CLIP_SECONDS) / 1e9 / HBM_PEAK_GBS,
             },
             "cpu_baseline": cpu,

@@ -123,9 +123,10 @@ int serhip_whisper_logmel(serhip_ctx* ctx, const float* audio_dev, int32_t n_cli
  * serhip_fast_features is bracketed by an event pair; serhip_profile_read waits
  * for the recorded launches of one kind, returns their summed duration and
  * count, and forgets them. */
-#define SERHIP_KERNEL_STFT_FRAMES 0     /* k_stft_frames   (framing+FFT+mel+peaks)  */
-#define SERHIP_KERNEL_SEGMENT_FINISH 1  /* k_segment_finish (MFCC, tuning, chroma)   */
-#define SERHIP_KERNEL_DFT_FRAMES 2      /* k_dft_frames    (segments < 2048 samples) */
+#define SERHIP_KERNEL_STFT_FRAMES 0     /* k_stft_frames    (framing+FFT+|X|+peaks)            */
+#define SERHIP_KERNEL_SEGMENT_FINISH 1  /* k_segment_finish (tuning / MFCC + time means)        */
+#define SERHIP_KERNEL_DFT_FRAMES 2      /* k_dft_frames     (segments < 2048 samples)           */
+#define SERHIP_KERNEL_PROJECT_FRAMES 3  /* k_project_frames (mel + chroma projections on MFMA)  */
 int serhip_profile_enable(serhip_ctx* ctx, int on);
 int serhip_profile_read(serhip_ctx* ctx, int kind, double* total_ms, int64_t* launches);
 

@@ -16,5 +16,5 @@ for name, fl in (("all", FeatureFlags(tonnetz=False)), ("mfcc+mel", FeatureFlags
     for _ in range(5): eng.features(audio, offs, lens, 16000, fl)
     torch.cuda.synchronize()
     eng._ctx.profile_enable(False)
-    k1, n1 = eng._ctx.profile_read(0); k2, n2 = eng._ctx.profile_read(1)
-    print(f"{name:14s} K1 {k1/5:.3f} ms/step ({n1} launches)  K2 {k2/5:.3f} ms/step  -> {n*94/(k1/5*1e-3)/1e6:.1f} Mframes/s K1")
+    k1, n1 = eng._ctx.profile_read(0); k2, n2 = eng._ctx.profile_read(1); k3, n3 = eng._ctx.profile_read(3)
+    print(f"{name:14s} K1 {k1/5:.3f} ms/step ({n1} launches)  Kfin {k2/5:.3f} ms/step  Kproj {k3/5:.3f} ms/step  total {(k1+k2+k3)/5:.3f}")

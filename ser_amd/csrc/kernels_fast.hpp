@@ -25,10 +25,9 @@ namespace serhip {
 // LDS and each owns an 8.5 KB transpose buffer; 12 waves = 3 per SIMD at <= 168 VGPRs.
 constexpr int kWaves = SERHIP_K1_WAVES; // waves per workgroup in k_stft_frames
 constexpr int kFramesPerBlock = 8 * kWaves;   // STFT frames per workgroup
-constexpr int kBufC = 1152;            // complex slots of one wave's LDS buffer (transposes need 16 x 68; |X|^2 + |X| + peaks 2304 floats)
-constexpr int kMelWCap = 3072;         // capacity of the 4-aligned sparse mel weight stream
+constexpr int kBufC = 1088;            // complex slots of one wave's LDS buffer (16 rows x stride 68)
+constexpr int kGroups = 65;            // 16-bin groups covering bins 0..1039 (1025 used)
 constexpr int kPeakLdsCap = 3072;      // peaks staged in LDS by k_segment_finish
-constexpr int kChromaTableStride = 1025 * 12 + 4;  // floats per tuning in the chroma table ([k][12], 16-B rows)
 
 // per-segment descriptor (device copy of what the host planned)
 struct SegDesc {
@@ -48,11 +47,11 @@ struct PlanTables {
     const v2f* twB;       // [16][4]   W_64^(m2*j1)
     const v2f* twU;       // [8][64]   W_2048^(lane+64r)
     const v2f* win;       // [16][64]  Hann pairs (w[128n1+2l], w[128n1+2l+1])
-    const float* mel_w;   // sparse mel weights, filter-major, each filter zero-padded to 4-aligned bins;
-                          // floats 0..3 are a shared zero group
-    const int4* mel_rng;  // [128] (first bin & ~3, groups of 4 taps, offset into mel_w, 0)
-    int mel_nnz;
-    const float* chroma;  // [101][kChromaTableStride]: per tuning [bin][12]
+    // B operands of k_project_frames in v_mfma_f32_16x16x4_f32 order: group G = 16 bins, lane
+    // (kk = lane>>4, j = lane&15) holds float4 {w[16G+4kk+u][j]}, u = 0..3
+    const float4* chroma_b;  // [101 tunings][65 groups][64 lanes]
+    const float4* mel_b;     // per 16-filter block b: [ghi-glo+1 groups][64 lanes] at group offset off
+    const int4* mel_blk;     // [9] {glo, ghi, off, 0} per block; entry 8 = sentinel {INT_MAX, INT_MAX, 0, 0}
     const float* dct;     // [40][128]
     const double* edges;  // [101] histogram edges np.linspace(-0.5, 0.5, 101)
     const double* mel_f;  // [130] mel band edges in Hz (generic path)
@@ -67,6 +66,8 @@ struct Scratch {
     float* mel;           // [frames][128]
     v2f* peaks;           // [frames][peak_cap]  (pitch, mag)
     int* peak_cnt;        // [frames]
+    float* chroma_norm;   // [frames][16]  per-frame inf-normalised chroma (classes 12..15 unused)
+    int* tuning_idx;      // [segments of the chunk]
     int peak_cap;         // peak slots per frame
 };
 
@@ -129,7 +130,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     __shared__ v2f s_twU[8 * 64];
     __shared__ v2f s_win[16 * 64];
     __shared__ v2f s_twB[16 * 4];
-    __shared__ __attribute__((aligned(16))) float s_melw[kMelWCap];
     __shared__ __attribute__((aligned(16))) v2f s_buf[kWaves][kBufC];
 
     const int tid = threadIdx.x;
@@ -145,18 +145,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     }
     for (int i = tid; i < 8 * 64; i += kWaves * 64) s_twU[i] = tb.twU[i];
     if (tid < 64) s_twB[tid] = tb.twB[tid];
-    for (int i = tid; i < tb.mel_nnz; i += kWaves * 64) s_melw[i] = tb.mel_w[i];
     __syncthreads();
 
     v2f* buf = s_buf[wave];
     float* fbuf = reinterpret_cast<float*>(buf);
-    float* sP = fbuf;            // |X|^2, bins 0..1024 (+3 zero pads), natural order
-    float* sM = fbuf + 1028;     // |X|,   bins 0..1024
+    float* sM = fbuf;            // |X|, bins 0..1024, natural order
 
     const float* seg_audio = audio + sd.offset;
     const bool aligned = ((reinterpret_cast<uintptr_t>(seg_audio) & 7u) == 0);
-    const int4 rng0 = tb.mel_rng[lane];
-    const int4 rng1 = tb.mel_rng[127 - lane];
     const int q = lane & 3;
     const float sg1 = (q & 2) ? -1.0f : 1.0f;
     const float sg2 = (q & 1) ? -1.0f : 1.0f;
@@ -164,7 +160,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     const int k1b = lane >> 2;
     const double sr_d = static_cast<double>(tb.sample_rate);
     const bool want_chroma = (tb.flags & 2u) != 0;
-    const bool want_mel = (tb.flags & 5u) != 0;
+    const bool want_proj = (tb.flags & 7u) != 0;   // any of mfcc / chroma / mel needs the magnitudes
 
     const int t_end = min(t_begin + kFramesPerBlock, sd.n_stft);
     // frame t covers segment samples [t*512 - 1024, t*512 + 1024); lane l holds the 16 sample
@@ -257,52 +253,20 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             const int k = lane + 64 * r;
             sM[k] = mlo[r];
             sM[1024 - k] = mhi[r];
-            sP[k] = mlo[r] * mlo[r];            // np.abs(D)**2: the square of the rounded magnitude
-            sP[1024 - k] = mhi[r] * mhi[r];
             cmax = fmaxf(cmax, fmaxf(mlo[r], mhi[r]));
         }
-        if (lane == 0) {
-            sM[512] = m512;
-            sP[512] = m512 * m512;
-        }
-        if (lane < 3) sP[1025 + lane] = 0.0f;   // the 4-wide mel reads may touch bins 1025..1027
+        if (lane == 0) sM[512] = m512;
         wave_lds_sync();
 
-        // ---- magnitudes for the chroma pass: lane l takes the 16 consecutive bins 16l..16l+15 from
-        // LDS (4 x ds_read_b128) and stores them with 4 x 16-byte stores (4 KB contiguous per wave)
-        if (want_chroma) {
-            const float4* mp = reinterpret_cast<const float4*>(sM + 16 * lane);
-            float4* mrow = reinterpret_cast<float4*>(sc.mags + row * kBinStride + 16 * lane);
+        // ---- magnitudes for k_project_frames: a linear copy of sM, float4 chunk (lane + 64u) per lane
+        // (conflict-free ds_read_b128, 1 KB contiguous per store instruction); bin 1024 is stored with
+        // three zero pads so the last 16-bin group reads defined values
+        if (want_proj) {
+            const float4* mp = reinterpret_cast<const float4*>(sM);
+            float4* mrow = reinterpret_cast<float4*>(sc.mags + row * kBinStride);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) mrow[u] = mp[u];
-            if (lane == 0) sc.mags[row * kBinStride + 1024] = mhi[0];
-        }
-
-        // ---- sparse Slaney mel projection: lane owns filters `lane` and `127 - lane`.  A filter's
-        // taps are consecutive bins, so weights and powers are read four at a time (ds_read_b128)
-        // from 4-aligned starts; lanes whose filter is exhausted read a shared zero group.
-        if (want_mel) {
-            float acc0 = 0.0f, acc1 = 0.0f;
-            const int nmax4 = max(rng0.y, rng1.y);
-#pragma unroll 2
-            for (int g = 0; g < nmax4; ++g) {
-                const bool in0 = g < rng0.y, in1 = g < rng1.y;
-                const float4 w0 = *reinterpret_cast<const float4*>(s_melw + (in0 ? rng0.z + 4 * g : 0));
-                const float4 p0 = *reinterpret_cast<const float4*>(sP + (in0 ? rng0.x + 4 * g : 0));
-                const float4 w1 = *reinterpret_cast<const float4*>(s_melw + (in1 ? rng1.z + 4 * g : 0));
-                const float4 p1 = *reinterpret_cast<const float4*>(sP + (in1 ? rng1.x + 4 * g : 0));
-                acc0 = fmaf(w0.x, p0.x, acc0);
-                acc0 = fmaf(w0.y, p0.y, acc0);
-                acc0 = fmaf(w0.z, p0.z, acc0);
-                acc0 = fmaf(w0.w, p0.w, acc0);
-                acc1 = fmaf(w1.x, p1.x, acc1);
-                acc1 = fmaf(w1.y, p1.y, acc1);
-                acc1 = fmaf(w1.z, p1.z, acc1);
-                acc1 = fmaf(w1.w, p1.w, acc1);
-            }
-            float* melrow = sc.mel + (static_cast<size_t>(sd.mel_base) + t) * kMels;
-            melrow[lane] = acc0;
-            melrow[127 - lane] = acc1;
+            for (int u = 0; u < 4; ++u) mrow[lane + 64 * u] = mp[lane + 64 * u];
+            if (lane == 0) mrow[256] = float4{mhi[0], 0.0f, 0.0f, 0.0f};
         }
 
         // ---- piptrack peaks (bins kmin..kmax), threshold 0.1 * column max.  Pass 1 finds the local
@@ -311,7 +275,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         if (want_chroma) {
             cmax = wave_max(cmax);
             const float ref = 0.1f * cmax;
-            int* cand = reinterpret_cast<int*>(fbuf + 2056);   // behind sP and sM
+            int* cand = reinterpret_cast<int*>(fbuf + 1032);   // behind sM
             int base = 0;
             for (int r = 0; 64 * r <= tb.kmax; ++r) {
                 const int k = lane + 64 * r;
@@ -372,9 +336,11 @@ __device__ __forceinline__ int tuning_bin(float r, const double* __restrict__ ed
     return i;
 }
 
+// kMode 0: whole finish for one segment (generic path); 1: tuning estimate only; 2: reductions only
+template <int kMode>
 struct FinishShared {
-    float fb[kBins * kChroma + 4];    // chroma filterbank of the selected tuning, [bin][12]
-    v2f peaks[kPeakLdsCap];
+    float fb[kMode == 0 ? kBins * kChroma + 4 : 4];   // chroma filterbank of the selected tuning, [bin][12]
+    v2f peaks[kMode == 2 ? 1 : kPeakLdsCap];
     unsigned hist[256];
     float red[64];
     int ired[8];
@@ -389,8 +355,8 @@ struct FinishShared {
 };
 
 // iterate over all peaks of the segment; F is called as f(pitch_mag)
-template <typename F>
-__device__ __forceinline__ void for_each_peak(const FinishShared& sh, bool in_lds, const Scratch& sc,
+template <typename Sh, typename F>
+__device__ __forceinline__ void for_each_peak(const Sh& sh, bool in_lds, const Scratch& sc,
                                               const SegDesc& sd, int peak_cap, F f) {
     if (in_lds) {
         for (int i = threadIdx.x; i < sh.n_peaks; i += blockDim.x) f(sh.peaks[i]);
@@ -405,7 +371,8 @@ __device__ __forceinline__ void for_each_peak(const FinishShared& sh, bool in_ld
 }
 
 // k-th smallest peak magnitude (0-based) by 4-pass 8-bit radix select; all threads return it
-__device__ float select_kth(FinishShared& sh, bool in_lds, const Scratch& sc, const SegDesc& sd,
+template <typename Sh>
+__device__ float select_kth(Sh& sh, bool in_lds, const Scratch& sc, const SegDesc& sd,
                             int peak_cap, unsigned k) {
     unsigned prefix = 0, mask = 0;
     for (int pass = 0; pass < 4; ++pass) {
@@ -462,11 +429,15 @@ __device__ void chroma_column_dev(int k, int n_fft, int sr, double tuning, float
 
 // ---------------------------------------------------------------------------------------
 // k_segment_finish: one workgroup (256 threads) per segment
+//   <0> generic path (segments < 2048 samples): mel/MFCC, tuning, on-device filterbank, chroma
+//   <1> fast path, before k_project_frames: tuning estimate -> sc.tuning_idx[segment]
+//   <2> fast path, after  k_project_frames: mel/MFCC reductions + time mean of the per-frame chroma
 // ---------------------------------------------------------------------------------------
+template <int kMode>
 __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __restrict__ segs, PlanTables tb,
                                                         Scratch sc, float* __restrict__ out,
                                                         float* __restrict__ tuning_out, int out_dim) {
-    __shared__ FinishShared sh;
+    __shared__ FinishShared<kMode> sh;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -481,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
     const int nbins = 1 + sd.n_fft / 2;
 
     // ---- mel mean and MFCC (power_to_db, top_db=80 vs the segment max, DCT of the time mean)
-    if (want_mfcc || want_mel) {
+    if (kMode != 1 && (want_mfcc || want_mel)) {
         const int m = tid & 127, half = tid >> 7;
         const float* mel = sc.mel + static_cast<size_t>(sd.mel_base) * kMels;
         // time sums are accumulated in double (the reference's float32 pairwise sums are within
@@ -521,9 +492,28 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
             orow[off_mfcc + tid] = static_cast<float>(acc);
         }
     }
-    if (want_contrast && tid < 7) orow[off_contrast + tid] = 0.0f;
+    if (kMode != 1 && want_contrast && tid < 7) orow[off_contrast + tid] = 0.0f;
     if (!want_chroma) {
-        if (tuning_out && tid == 0) tuning_out[sd.out_row] = 0.0f;
+        if (kMode != 2 && tuning_out && tid == 0) tuning_out[sd.out_row] = 0.0f;
+        return;
+    }
+    if constexpr (kMode == 2) {
+        // time mean of the per-frame normalised chroma written by k_project_frames:
+        // thread (c = tid & 15, part = tid >> 4) sums frames part, part + 16, ...
+        const int c = tid & 15, part = tid >> 4;
+        const float* cn = sc.chroma_norm + static_cast<size_t>(sd.stft_base) * 16;
+        float acc = 0.0f;
+        for (int t = part; t < sd.n_stft; t += 16) acc += cn[static_cast<size_t>(t) * 16 + c];
+        __syncthreads();
+        float* slots = reinterpret_cast<float*>(sh.melsum);   // 256 floats fit in melsum (2 x 128 doubles)
+        slots[part * 16 + c] = acc;
+        __syncthreads();
+        if (tid < kChroma) {
+            float s = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += slots[q * 16 + tid];
+            orow[off_chroma + tid] = s / static_cast<float>(sd.n_stft);
+        }
         return;
     }
 
@@ -579,13 +569,14 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         tuning_idx = sh.tuning_idx;
     }
     if (tuning_out && tid == 0) tuning_out[sd.out_row] = static_cast<float>(tb.edges[tuning_idx]);
+    if constexpr (kMode == 1) {
+        if (tid == 0) sc.tuning_idx[blockIdx.x] = tuning_idx;
+        return;
+    }
 
-    // ---- chroma filterbank of that tuning -> LDS, bin-major [k][12] (3 x ds_read_b128 per bin)
-    if (sd.n_fft == kNfft) {
-        const float4* src = reinterpret_cast<const float4*>(tb.chroma + static_cast<size_t>(tuning_idx) * kChromaTableStride);
-        float4* dst = reinterpret_cast<float4*>(sh.fb);
-        for (int i = tid; i < kBins * kChroma / 4; i += blockDim.x) dst[i] = src[i];
-    } else {
+    if constexpr (kMode == 0) {
+    // ---- chroma filterbank of that tuning, built on the device -> LDS, bin-major [k][12]
+    {
         const double tuning = tb.edges[tuning_idx];
         for (int k = tid; k < nbins; k += blockDim.x) {
             float col[12];
@@ -612,38 +603,7 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         float v[64];
 #pragma unroll
         for (int i = 0; i < 64; ++i) v[i] = 0.0f;
-        if (sd.n_fft == kNfft) {
-            // 1025 bins: two batches of 32 global loads, each issued before its FMAs
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float x[4][8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) x[f][r] = mrow[f][lane + 64 * (8 * half + r)];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float4* wp = reinterpret_cast<const float4*>(sh.fb + (lane + 64 * (8 * half + r)) * kChroma);
-                    const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-                    const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-#pragma unroll
-                    for (int f = 0; f < 4; ++f)
-#pragma unroll
-                        for (int c = 0; c < 12; ++c) v[f * 16 + c] = fmaf(w[c], x[f][r], v[f * 16 + c]);
-                }
-            }
-            if (lane == 0) {   // bin 1024
-                const float4* wp = reinterpret_cast<const float4*>(sh.fb + 1024 * kChroma);
-                const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-                const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const float xe = mrow[f][1024];
-#pragma unroll
-                    for (int c = 0; c < 12; ++c) v[f * 16 + c] = fmaf(w[c], xe, v[f * 16 + c]);
-                }
-            }
-        } else {
+        {
             for (int k = lane; k < nbins; k += 64) {
                 float x[4];
 #pragma unroll
@@ -685,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         const float s = (sh.chroma_acc[0][tid] + sh.chroma_acc[1][tid]) + (sh.chroma_acc[2][tid] + sh.chroma_acc[3][tid]);
         orow[off_chroma + tid] = s / static_cast<float>(sd.n_stft);
     }
+    }  // kMode == 0
 }
 
 }  // namespace serhip

@@ -14,6 +14,7 @@
 
 #include "kernels_fast.hpp"
 #include "kernels_generic.hpp"
+#include "kernels_project.hpp"
 #include "kernels_whisper.hpp"
 #include "tables.hpp"
 
@@ -45,8 +46,10 @@ int feature_dim_of(uint32_t flags) {
 // host tables of the fast plan (n_fft 2048)
 struct HostTables {
     std::vector<v2f> twA, twB, twU, win;
-    std::vector<float> mel_dense, mel_w, chroma, dct;
-    std::vector<int4> mel_rng;
+    std::vector<float> mel_dense, dct;
+    std::vector<float> chroma_b;   // [101][65][64][4]  MFMA B operand order (kernels_project.hpp)
+    std::vector<float> mel_b;      // per 16-filter block, the 16-bin groups it touches, [64][4] each
+    int mel_glo[8], mel_ghi[8], mel_off[8];
     std::vector<double> edges, mel_f, window;
     int kmin = 0, kmax = -1;
 };
@@ -77,24 +80,34 @@ void build_host_tables(int sr, HostTables& h, bool with_chroma) {
             h.win[n1 * 64 + l] = v2f{static_cast<float>(h.window[128 * n1 + 2 * l]),
                                      static_cast<float>(h.window[128 * n1 + 2 * l + 1])};
     h.mel_dense = mel_filterbank(sr, kNfft, kMels);
-    // sparse stream for k_stft_frames: floats 0..3 are a zero group; every filter starts at a
-    // 4-aligned bin and is zero-padded to whole groups of 4 taps (16-byte LDS reads)
-    h.mel_rng.assign(kMels, int4{0, 0, 0, 0});
-    h.mel_w.assign(4, 0.0f);
-    for (int m = 0; m < kMels; ++m) {
-        int first = -1, last = -1;
-        for (int k = 0; k < kBins; ++k)
-            if (h.mel_dense[static_cast<size_t>(m) * kBins + k] != 0.0f) {
-                if (first < 0) first = k;
-                last = k;
-            }
-        if (first >= 0) {
-            const int start = first & ~3;
-            const int groups = (last - start + 4) / 4;
-            h.mel_rng[m] = int4{start, groups, static_cast<int>(h.mel_w.size()), 0};
-            for (int k = start; k < start + 4 * groups; ++k)
-                h.mel_w.push_back(k < kBins ? h.mel_dense[static_cast<size_t>(m) * kBins + k] : 0.0f);
+    // B operands of k_project_frames: lane (kk = lane>>4, j = lane&15) of group G holds the weights of
+    // filter/class j for bins 16G + 4kk + u, u = 0..3.  Block b = filters 16b..16b+15 keeps only the
+    // contiguous run of groups in which one of its filters is nonzero (the Slaney bank is banded).
+    h.mel_b.clear();
+    for (int b = 0; b < 8; ++b) {
+        int glo = -1, ghi = -1;
+        for (int m = 16 * b; m < 16 * b + 16; ++m)
+            for (int k = 0; k < kBins; ++k)
+                if (h.mel_dense[static_cast<size_t>(m) * kBins + k] != 0.0f) {
+                    if (glo < 0 || k / 16 < glo) glo = k / 16;
+                    if (k / 16 > ghi) ghi = k / 16;
+                }
+        if (glo < 0) {   // an all-zero block (cannot happen for 128 Slaney filters; keep the kernel's test false)
+            h.mel_glo[b] = 1;
+            h.mel_ghi[b] = 0;
+            h.mel_off[b] = 0;
+            continue;
         }
+        h.mel_glo[b] = glo;
+        h.mel_ghi[b] = ghi;
+        h.mel_off[b] = static_cast<int>(h.mel_b.size() / 256);
+        for (int G = glo; G <= ghi; ++G)
+            for (int l = 0; l < 64; ++l)
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 16 * G + 4 * (l >> 4) + u;
+                    const int m = 16 * b + (l & 15);
+                    h.mel_b.push_back(k < kBins ? h.mel_dense[static_cast<size_t>(m) * kBins + k] : 0.0f);
+                }
     }
     h.dct = dct_ortho(kMfcc, kMels);
     h.edges.resize(kTunings);
@@ -102,9 +115,18 @@ void build_host_tables(int sr, HostTables& h, bool with_chroma) {
     h.mel_f = mel_edges(kMels, static_cast<double>(sr) / 2);
     piptrack_bin_range(sr, kNfft, &h.kmin, &h.kmax);
     if (with_chroma) {
-        h.chroma.assign(static_cast<size_t>(kTunings) * kChromaTableStride, 0.0f);
-        for (int i = 0; i < kTunings; ++i)
-            chroma_filterbank(sr, kNfft, h.edges[i], h.chroma.data() + static_cast<size_t>(i) * kChromaTableStride);
+        h.chroma_b.assign(static_cast<size_t>(kTunings) * kGroups * 256, 0.0f);
+        std::vector<float> fb(static_cast<size_t>(kBins) * kChroma);
+        for (int i = 0; i < kTunings; ++i) {
+            chroma_filterbank(sr, kNfft, h.edges[i], fb.data());   // bin-major [k][12]
+            float* dst = h.chroma_b.data() + static_cast<size_t>(i) * kGroups * 256;
+            for (int G = 0; G < kGroups; ++G)
+                for (int l = 0; l < 64; ++l)
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = 16 * G + 4 * (l >> 4) + u, c = l & 15;
+                        if (k < kBins && c < kChroma) dst[(G * 64 + l) * 4 + u] = fb[static_cast<size_t>(k) * kChroma + c];
+                    }
+        }
     }
 }
 
@@ -179,9 +201,9 @@ int ensure_staging(serhip_ctx* ctx, size_t bytes) {
 }
 
 struct ScratchLayout {
-    size_t mags, mel, peaks, cnt, total;
+    size_t mags, mel, peaks, cnt, cnorm, tidx, total;
 };
-ScratchLayout scratch_layout(size_t frames, int peak_cap) {
+ScratchLayout scratch_layout(size_t frames, int peak_cap, size_t segs) {
     ScratchLayout l{};
     size_t o = 0;
     l.mags = o;
@@ -192,6 +214,10 @@ ScratchLayout scratch_layout(size_t frames, int peak_cap) {
     o = align_up(o + frames * static_cast<size_t>(peak_cap) * sizeof(v2f), 256);
     l.cnt = o;
     o = align_up(o + frames * sizeof(int), 256);
+    l.cnorm = o;
+    o = align_up(o + frames * 16 * sizeof(float), 256);
+    l.tidx = o;
+    o = align_up(o + segs * sizeof(int), 256);
     l.total = o;
     return l;
 }
@@ -201,6 +227,8 @@ Scratch scratch_at(char* base, const ScratchLayout& l, int peak_cap) {
     s.mel = reinterpret_cast<float*>(base + l.mel);
     s.peaks = reinterpret_cast<v2f*>(base + l.peaks);
     s.peak_cnt = reinterpret_cast<int*>(base + l.cnt);
+    s.chroma_norm = reinterpret_cast<float*>(base + l.cnorm);
+    s.tuning_idx = reinterpret_cast<int*>(base + l.tidx);
     s.peak_cap = peak_cap;
     return s;
 }
@@ -381,11 +409,24 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
     HostTables h;
     const bool with_chroma = (feature_flags & SERHIP_FEAT_CHROMA) != 0;
     build_host_tables(sample_rate, h, with_chroma);
-    if (static_cast<int>(h.mel_w.size()) > kMelWCap)
-        return fail(SERHIP_E_UNSUPPORTED, "serhip_plan_fast: mel filterbank has too many taps for this sample rate");
     if (with_chroma && h.kmax >= kBins - 1)
         return fail(SERHIP_E_UNSUPPORTED,
                     "serhip_plan_fast: piptrack range reaches the Nyquist bin (sample_rate <= 8000) -- not implemented");
+
+    // k_project_frames keeps two mel blocks live at a time: runs must advance monotonically and block
+    // b + 2 must start after block b ends (true for the Slaney bank at any practical sample rate)
+    int4 blk[9];
+    for (int b = 0; b < 8; ++b) blk[b] = int4{h.mel_glo[b], h.mel_ghi[b], h.mel_off[b], 0};
+    blk[8] = int4{0x7fffffff, 0x7fffffff, 0, 0};
+    if (feature_flags & (SERHIP_FEAT_MFCC | SERHIP_FEAT_MEL))
+        for (int b = 0; b < 8; ++b) {
+            const bool bad = h.mel_glo[b] > h.mel_ghi[b] || (b > 0 && (h.mel_glo[b] < h.mel_glo[b - 1] || h.mel_ghi[b] < h.mel_ghi[b - 1])) ||
+                             (b > 1 && h.mel_glo[b] <= h.mel_ghi[b - 2]);
+            if (bad)
+                return fail(SERHIP_E_UNSUPPORTED,
+                            "serhip_plan_fast: mel filterbank layout at this sample rate is not supported (filter block " +
+                                std::to_string(b) + ")");
+        }
 
     // one device blob, sub-allocated
     size_t o = 0;
@@ -396,9 +437,8 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
     };
     const size_t o_twA = take(h.twA.size() * sizeof(v2f)), o_twB = take(h.twB.size() * sizeof(v2f)),
                  o_twU = take(h.twU.size() * sizeof(v2f)), o_win = take(h.win.size() * sizeof(v2f)),
-                 o_melw = take(std::max<size_t>(h.mel_w.size(), 1) * sizeof(float)),
-                 o_rng = take(h.mel_rng.size() * sizeof(int4)),
-                 o_chroma = take(std::max<size_t>(h.chroma.size(), 1) * sizeof(float)),
+                 o_melb = take(std::max<size_t>(h.mel_b.size(), 4) * sizeof(float)), o_blk = take(9 * sizeof(int4)),
+                 o_chroma = take(std::max<size_t>(h.chroma_b.size(), 4) * sizeof(float)),
                  o_dct = take(h.dct.size() * sizeof(float)), o_edges = take(h.edges.size() * sizeof(double)),
                  o_melf = take(h.mel_f.size() * sizeof(double));
     std::vector<char> blob(o, 0);
@@ -409,9 +449,9 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
     put(o_twB, h.twB.data(), h.twB.size() * sizeof(v2f));
     put(o_twU, h.twU.data(), h.twU.size() * sizeof(v2f));
     put(o_win, h.win.data(), h.win.size() * sizeof(v2f));
-    put(o_melw, h.mel_w.data(), h.mel_w.size() * sizeof(float));
-    put(o_rng, h.mel_rng.data(), h.mel_rng.size() * sizeof(int4));
-    put(o_chroma, h.chroma.data(), h.chroma.size() * sizeof(float));
+    put(o_melb, h.mel_b.data(), h.mel_b.size() * sizeof(float));
+    put(o_blk, blk, sizeof(blk));
+    put(o_chroma, h.chroma_b.data(), h.chroma_b.size() * sizeof(float));
     put(o_dct, h.dct.data(), h.dct.size() * sizeof(float));
     put(o_edges, h.edges.data(), h.edges.size() * sizeof(double));
     put(o_melf, h.mel_f.data(), h.mel_f.size() * sizeof(double));
@@ -436,13 +476,12 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
     tb.twB = reinterpret_cast<const v2f*>(d + o_twB);
     tb.twU = reinterpret_cast<const v2f*>(d + o_twU);
     tb.win = reinterpret_cast<const v2f*>(d + o_win);
-    tb.mel_w = reinterpret_cast<const float*>(d + o_melw);
-    tb.mel_rng = reinterpret_cast<const int4*>(d + o_rng);
-    tb.chroma = reinterpret_cast<const float*>(d + o_chroma);
+    tb.mel_b = reinterpret_cast<const float4*>(d + o_melb);
+    tb.chroma_b = reinterpret_cast<const float4*>(d + o_chroma);
+    tb.mel_blk = reinterpret_cast<const int4*>(d + o_blk);
     tb.dct = reinterpret_cast<const float*>(d + o_dct);
     tb.edges = reinterpret_cast<const double*>(d + o_edges);
     tb.mel_f = reinterpret_cast<const double*>(d + o_melf);
-    tb.mel_nnz = static_cast<int>(h.mel_w.size());
     tb.kmin = h.kmin;
     tb.kmax = h.kmax;
     tb.sample_rate = sample_rate;
@@ -565,8 +604,11 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
 
     // ---- workspace: [descriptors | fast scratch | generic scratch]
     const size_t desc_bytes = align_up(descs.size() * sizeof(SegDesc), 256);
-    const ScratchLayout lf = scratch_layout(max_chunk_frames, plan->peak_cap);
-    const ScratchLayout lg = scratch_layout(std::max(gen_frames_max, gen_mel_max), kGenericPeakCap);
+    size_t max_chunk_segs = 0;
+    for (const Chunk& c : chunks)
+        if (!c.generic) max_chunk_segs = std::max(max_chunk_segs, static_cast<size_t>(c.count));
+    const ScratchLayout lf = scratch_layout(max_chunk_frames, plan->peak_cap, max_chunk_segs);
+    const ScratchLayout lg = scratch_layout(std::max(gen_frames_max, gen_mel_max), kGenericPeakCap, 0);
     int rc = ensure_workspace(ctx, desc_bytes + lf.total + lg.total);
     if (rc != SERHIP_OK) return rc;
     rc = ensure_staging(ctx, descs.size() * sizeof(SegDesc));
@@ -580,6 +622,8 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
     const Scratch sg = scratch_at(ws + desc_bytes + lf.total, lg, kGenericPeakCap);
 
     // ---- launches
+    const bool want_chroma = (plan->flags & SERHIP_FEAT_CHROMA) != 0;
+    const bool want_proj = (plan->flags & (SERHIP_FEAT_MFCC | SERHIP_FEAT_CHROMA | SERHIP_FEAT_MEL)) != 0;
     for (const Chunk& c : chunks) {
         const SegDesc* dd = d_descs + c.first;
         if (!c.generic) {
@@ -588,10 +632,22 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
                 LaunchTimer lt(ctx, SERHIP_KERNEL_STFT_FRAMES, stream);
                 hipLaunchKernelGGL(k_stft_frames, grid, dim3(kWaves * 64), 0, stream, audio_dev, dd, plan->tb, sf);
             }
+            const dim3 segs_grid(static_cast<unsigned>(c.count));
+            if (want_chroma || tuning_dev) {   // tuning estimate per segment (zeros when chroma is off)
+                LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream);
+                hipLaunchKernelGGL(k_segment_finish<1>, segs_grid, dim3(256), 0, stream, dd, plan->tb, sf, out_dev,
+                                   tuning_dev, plan->dim);
+            }
+            if (want_proj) {
+                const int tiles = (c.max_frames + kProjTile - 1) / kProjTile;
+                LaunchTimer lt(ctx, SERHIP_KERNEL_PROJECT_FRAMES, stream);
+                hipLaunchKernelGGL(k_project_frames, dim3((tiles + 3) / 4, static_cast<unsigned>(c.count)), dim3(256), 0,
+                                   stream, dd, plan->tb, sf);
+            }
             {
                 LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream);
-                hipLaunchKernelGGL(k_segment_finish, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
-                                   plan->tb, sf, out_dev, tuning_dev, plan->dim);
+                hipLaunchKernelGGL(k_segment_finish<2>, segs_grid, dim3(256), 0, stream, dd, plan->tb, sf, out_dev,
+                                   tuning_dev, plan->dim);
             }
         } else {
             const dim3 grid(static_cast<unsigned>(c.max_frames), static_cast<unsigned>(c.count));
@@ -601,7 +657,7 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
             }
             {
                 LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream);
-                hipLaunchKernelGGL(k_segment_finish, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
+                hipLaunchKernelGGL(k_segment_finish<0>, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
                                    plan->tb, sg, out_dev, tuning_dev, plan->dim);
             }
         }
