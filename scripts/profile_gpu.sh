@@ -21,4 +21,4 @@ python3 $ROOT/scripts/summarize_profile.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>
 # keep only the small artefacts (gpurun copies back at most 64 MiB)
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_$TAG.csv" \;
 rm -rf "$OUT"/trace "$OUT"/pmc[0-9]*
-grep -E "k_stft_frames|k_segment_finish" -A 26 "$OUT/summary.txt" | head -70
+grep -E "k_stft_frames|k_segment_finish|k_project_frames" -A 26 "$OUT/summary.txt" | head -120

@@ -9,12 +9,16 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
 
 def short(name):
-    for key in ("k_stft_frames", "k_segment_finish", "k_dft_frames", "k_pool_windows", "k_whisper_frames",
+    m = re.search(r"k_segment_finish<(\d)>", name) or re.search(r"k_segment_finishILi(\d)E", name)
+    if m:
+        return f"k_segment_finish<{m.group(1)}>"
+    for key in ("k_project_frames", "k_stft_frames", "k_segment_finish", "k_dft_frames", "k_pool_windows", "k_whisper_frames",
                 "k_whisper_finalize"):
         if key in name:
             return key

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     // frame t covers segment samples [t*512 - 1024, t*512 + 1024); lane l holds the 16 sample
     // pairs 128*n1 + 2*l.  Out-of-range samples are the zero padding of librosa.stft(center=True).
     auto load_frame = [&](int t, v2f (&dst)[16]) {
-        const long long fs = static_cast<long long>(t) * kHop - kNfft / 2;
+        const int fs = t * kHop - kNfft / 2;   // < 2^31: the host rejects longer segments
         if (fs >= 0 && fs + kNfft <= sd.len) {
             const float* p = seg_audio + fs + 2 * lane;
             if (aligned) {
@@ -177,22 +177,23 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
                 for (int n1 = 0; n1 < 16; ++n1) dst[n1] = v2f{p[128 * n1], p[128 * n1 + 1]};
             }
         } else {
+            // frame overlaps the zero padding: clamped (always valid) addresses, values masked afterwards
+            const int hi = sd.len - 1;
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
-                const long long s = fs + 128 * n1 + 2 * lane;
-                const float a = (s >= 0 && s < sd.len) ? seg_audio[s] : 0.0f;
-                const float b = (s + 1 >= 0 && s + 1 < sd.len) ? seg_audio[s + 1] : 0.0f;
-                dst[n1] = v2f{a, b};
+                const int s = fs + 128 * n1 + 2 * lane;
+                const float a = seg_audio[min(max(s, 0), hi)];
+                const float b = seg_audio[min(max(s + 1, 0), hi)];
+                dst[n1] = v2f{static_cast<unsigned>(s) < static_cast<unsigned>(sd.len) ? a : 0.0f,
+                              static_cast<unsigned>(s + 1) < static_cast<unsigned>(sd.len) ? b : 0.0f};
             }
         }
     };
-    v2f vnext[16];
-    if (t_begin + wave < t_end) load_frame(t_begin + wave, vnext);
-    for (int t = t_begin + wave; t < t_end; t += kWaves) {
-        v2f v[16];
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = vnext[n1];
-        if (t + kWaves < t_end) load_frame(t + kWaves, vnext);   // prefetch: latency hides behind this frame's FFT
+    const v2f rot3 = (q == 3) ? v2f{0.0f, -1.0f} : v2f{1.0f, 0.0f};   // lane 3 of a quad turns by -i
+    // one frame, consumed from v (the raw sample pairs loaded by load_frame)
+    auto process_frame = [&](int t, v2f (&v)[16]) {
+        // s_win holds HALF the Hann window: the FFT is linear and halving is exact, so the unpack below
+        // needs no 0.5 factors
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = v[n1] * s_win[n1 * 64 + lane];
 
@@ -214,8 +215,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             v2f x = v[SERHIP_REV4(j1)];
             if (j1 > 0) x = cmul(x, s_twB[j1 * 4 + q]);
             const v2f p = v2f{dpp_mov<0x4E>(x.x), dpp_mov<0x4E>(x.y)};   // lane ^ 2
-            v2f u = p + sg1 * x;
-            if (q == 3) u = mul_neg_i(u);
+            const v2f u = cmul(p + sg1 * x, rot3);
             const v2f p2 = v2f{dpp_mov<0xB1>(u.x), dpp_mov<0xB1>(u.y)};  // lane ^ 1
             const v2f w = p2 + sg2 * u;
             // Z[k], k = k1 + 16*j1 + 256*j2, stored at k + 4*(k>>8)
@@ -234,15 +234,15 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             const v2f e2 = v2f{za.x + zb.x, za.y - zb.y};       // 2E
             const v2f o2 = v2f{za.y + zb.y, zb.x - za.x};       // 2O
             const v2f t2 = cmul(o2, s_twU[r * 64 + lane]);
-            const v2f xlo = 0.5f * (e2 + t2);
-            const v2f xhi = 0.5f * (e2 - t2);
+            const v2f xlo = e2 + t2;
+            const v2f xhi = e2 - t2;
             mlo[r] = __builtin_amdgcn_sqrtf(xlo.x * xlo.x + xlo.y * xlo.y);   // v_sqrt_f32, <= 1 ulp
             mhi[r] = __builtin_amdgcn_sqrtf(xhi.x * xhi.x + xhi.y * xhi.y);
         }
         float m512 = 0.0f;
         if (lane == 0) {
             const v2f z = buf[512 + 8];
-            m512 = __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);
+            m512 = 2.0f * __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);   // Z is half-scaled
         }
         wave_lds_sync();  // every lane has read Z before the buffer is reused
 
@@ -277,20 +277,22 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             const float ref = 0.1f * cmax;
             int* cand = reinterpret_cast<int*>(fbuf + 1032);   // behind sM
             int base = 0;
-            for (int r = 0; 64 * r <= tb.kmax; ++r) {
+            // librosa thresholds S below ref to 0 before localmax; with s0 > ref that is the same as
+            // comparing the raw neighbours (a neighbour <= ref is < s0 either way)
+            auto scan_stripe = [&](int r, float s0) {
                 const int k = lane + 64 * r;
+                const bool cand_ok = (s0 > ref) && (k >= tb.kmin) && (k <= tb.kmax);
+                if (__ballot(cand_ok) == 0ull) return;   // wave-uniform: most stripes hold nothing above ref
                 bool is_peak = false;
-                if (k >= tb.kmin && k <= tb.kmax) {
-                    const float sm = sM[k - 1], s0 = sM[k], sp = sM[k + 1];
-                    const float tm = sm > ref ? sm : 0.0f;
-                    const float t0 = s0 > ref ? s0 : 0.0f;
-                    const float tp = sp > ref ? sp : 0.0f;
-                    is_peak = (t0 > tm) && (t0 >= tp);
-                }
+                if (cand_ok) is_peak = (s0 > sM[k - 1]) && (s0 >= sM[k + 1]);
                 const unsigned long long mask = __ballot(is_peak);
                 if (is_peak) cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = k;
                 base += __popcll(mask);
-            }
+            };
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (64 * r <= tb.kmax) scan_stripe(r, mlo[r]);
+            for (int r = 8; 64 * r <= tb.kmax; ++r) scan_stripe(r, sM[lane + 64 * r]);   // sample rates < 16 kHz
             wave_lds_sync();
             v2f* prow = sc.peaks + row * sc.peak_cap;
             for (int i = lane; i < base; i += 64) {
@@ -300,6 +302,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             if (lane == 0) sc.peak_cnt[row] = base;
         }
         wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
+    };
+
+    v2f vnext[16];
+    if (t_begin + wave < t_end) load_frame(t_begin + wave, vnext);
+    for (int t = t_begin + wave; t < t_end; t += kWaves) {
+        v2f v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = vnext[n1];
+        if (t + kWaves < t_end) load_frame(t + kWaves, vnext);   // prefetch: latency hides behind this frame's FFT
+        process_frame(t, v);
     }
 }
 

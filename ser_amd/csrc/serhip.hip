@@ -77,8 +77,8 @@ void build_host_tables(int sr, HostTables& h, bool with_chroma) {
     h.win.resize(16 * 64);
     for (int n1 = 0; n1 < 16; ++n1)
         for (int l = 0; l < 64; ++l)
-            h.win[n1 * 64 + l] = v2f{static_cast<float>(h.window[128 * n1 + 2 * l]),
-                                     static_cast<float>(h.window[128 * n1 + 2 * l + 1])};
+            h.win[n1 * 64 + l] = v2f{0.5f * static_cast<float>(h.window[128 * n1 + 2 * l]),        // half window:
+                                     0.5f * static_cast<float>(h.window[128 * n1 + 2 * l + 1])};   // see k_stft_frames
     h.mel_dense = mel_filterbank(sr, kNfft, kMels);
     // B operands of k_project_frames: lane (kk = lane>>4, j = lane&15) of group G holds the weights of
     // filter/class j for bins 16G + 4kk + u, u = 0..3.  Block b = filters 16b..16b+15 keeps only the
@@ -530,7 +530,7 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
     std::vector<SegDesc> descs;
     descs.reserve(static_cast<size_t>(n_seg));
     std::vector<SegDesc> generic;
-    size_t chunk_cap = ctx->chunk_frames ? ctx->chunk_frames : (static_cast<size_t>(1) << 18);
+    size_t chunk_cap = ctx->chunk_frames ? ctx->chunk_frames : (static_cast<size_t>(1) << 21);
     std::vector<Chunk> chunks;
     Chunk cur{0, 0, 0, false};
     size_t cur_frames = 0, max_chunk_frames = 0;
