@@ -20,4 +20,4 @@ for _ in range(5): eng.features(audio, offs, lens, 16000, fl)
 torch.cuda.synchronize()
 eng._ctx.profile_enable(False)
 k1, n1 = eng._ctx.profile_read(0); k2, n2 = eng._ctx.profile_read(1); k3, n3 = eng._ctx.profile_read(3)
-print(f"chunk={os.environ.get('SERHIP_CHUNK_FRAMES','default'):>8s} wall {wall:.3f} ms/step | K1 {k1/5:.3f} ({n1//5} launches) Kfin {k2/5:.3f} Kproj {k3/5:.3f} sum {(k1+k2+k3)/5:.3f}", flush=True)
+print(f"pipe={os.environ.get('SERHIP_PIPELINE','default')} chunk={os.environ.get('SERHIP_CHUNK_FRAMES','default'):>8s} wall {wall:.3f} ms/step | K1 {k1/5:.3f} ({n1//5} launches) Kfin {k2/5:.3f} Kproj {k3/5:.3f} sum {(k1+k2+k3)/5:.3f}", flush=True)

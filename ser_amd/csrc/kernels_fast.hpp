@@ -19,15 +19,19 @@
 namespace serhip {
 
 #ifndef SERHIP_K1_WAVES
-#define SERHIP_K1_WAVES 12
+#define SERHIP_K1_WAVES 16
 #endif
-// k_stft_frames runs ONE workgroup per CU: its waves share the 30 KB of twiddle/window/mel tables in
-// LDS and each owns an 8.5 KB transpose buffer; 12 waves = 3 per SIMD at <= 168 VGPRs.
+#ifndef SERHIP_K1_PREFETCH
+#define SERHIP_K1_PREFETCH 0   // 1: keep the next frame's samples in 32 more VGPRs (pays only below 16 waves)
+#endif
+// k_stft_frames runs ONE workgroup per CU: its waves share the 21 KB of twiddle/window tables in LDS and
+// each owns an 8.5 KB transpose buffer.  16 waves = 4 per SIMD at <= 128 VGPRs fill the 160 KB of LDS;
+// measured on MI355X (12.5k clips): 8 waves 4.2 ms, 12 waves 2.9 ms, 16 waves 2.8 ms.
 constexpr int kWaves = SERHIP_K1_WAVES; // waves per workgroup in k_stft_frames
 constexpr int kFramesPerBlock = 8 * kWaves;   // STFT frames per workgroup
 constexpr int kBufC = 1088;            // complex slots of one wave's LDS buffer (16 rows x stride 68)
 constexpr int kGroups = 65;            // 16-bin groups covering bins 0..1039 (1025 used)
-constexpr int kPeakLdsCap = 3072;      // peaks staged in LDS by k_segment_finish
+constexpr int kPeakLdsCap = 2048;      // peaks staged in LDS by k_segment_finish
 
 // per-segment descriptor (device copy of what the host planned)
 struct SegDesc {
@@ -50,8 +54,8 @@ struct PlanTables {
     // B operands of k_project_frames in v_mfma_f32_16x16x4_f32 order: group G = 16 bins, lane
     // (kk = lane>>4, j = lane&15) holds float4 {w[16G+4kk+u][j]}, u = 0..3
     const float4* chroma_b;  // [101 tunings][65 groups][64 lanes]
-    const float4* mel_b;     // per 16-filter block b: [ghi-glo+1 groups][64 lanes] at group offset off
-    const int4* mel_blk;     // [9] {glo, ghi, off, 0} per block; entry 8 = sentinel {INT_MAX, INT_MAX, 0, 0}
+    const float4* mel_b;     // rows of 64 lanes: row 0 all zeros, then per 16-filter block its live groups
+    const int4* mel_prog;    // [65] per group: {row of slot lo, row of slot hi, live mask (1 lo, 2 hi), retires}
     const float* dct;     // [40][128]
     const double* edges;  // [101] histogram edges np.linspace(-0.5, 0.5, 101)
     const double* mel_f;  // [130] mel band edges in Hz (generic path)
@@ -62,14 +66,25 @@ struct PlanTables {
 
 // per-chunk scratch (device pointers)
 struct Scratch {
-    float* mags;          // [frames][kBinStride]
-    float* mel;           // [frames][128]
+    float* mags;          // generic path: [frames][kBinStride]; fast path: tiled, see mags_tile_index
+    float* mel;           // [frames][128]  generic path: mel power; fast path: mel power in dB (k_project_frames)
+    float* mel_part;      // [frames/16][128]  fast path: mel power summed over the 16 frames of a tile
+    float* mel_dbmax;     // [frames/16][8]    fast path: max dB per (tile, 16-filter block)
     v2f* peaks;           // [frames][peak_cap]  (pitch, mag)
     int* peak_cnt;        // [frames]
     float* chroma_norm;   // [frames][16]  per-frame inf-normalised chroma (classes 12..15 unused)
     int* tuning_idx;      // [segments of the chunk]
     int peak_cap;         // peak slots per frame
 };
+
+// Fast-path magnitudes are stored in the order k_project_frames consumes them: frame slots in tiles of
+// 16, and inside a tile [group of 16 bins][frame][16 bins], so that the A operand of one MFMA group is
+// one contiguous 1 KB block.  Returns the float4 index of bins 4q..4q+3 of frame slot f.  Every
+// segment starts on a tile boundary (the host pads stft_base to a multiple of 16).
+constexpr int kTileBytes = kGroups * 1024;   // 66 560 B per 16 frames
+__host__ __device__ __forceinline__ size_t mags_tile_index(size_t f, int q) {
+    return ((f >> 4) * kGroups + static_cast<size_t>(q >> 2)) * 64 + (f & 15) * 4 + (q & 3);
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
@@ -263,10 +278,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         // three zero pads so the last 16-bin group reads defined values
         if (want_proj) {
             const float4* mp = reinterpret_cast<const float4*>(sM);
-            float4* mrow = reinterpret_cast<float4*>(sc.mags + row * kBinStride);
+            float4* m4 = reinterpret_cast<float4*>(sc.mags);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) mrow[lane + 64 * u] = mp[lane + 64 * u];
-            if (lane == 0) mrow[256] = float4{mhi[0], 0.0f, 0.0f, 0.0f};
+            for (int u = 0; u < 4; ++u) m4[mags_tile_index(row, lane + 64 * u)] = mp[lane + 64 * u];
+            if (lane == 0) m4[mags_tile_index(row, 256)] = float4{mhi[0], 0.0f, 0.0f, 0.0f};
         }
 
         // ---- piptrack peaks (bins kmin..kmax), threshold 0.1 * column max.  Pass 1 finds the local
@@ -304,6 +319,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
     };
 
+#if SERHIP_K1_PREFETCH
     v2f vnext[16];
     if (t_begin + wave < t_end) load_frame(t_begin + wave, vnext);
     for (int t = t_begin + wave; t < t_end; t += kWaves) {
@@ -313,6 +329,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         if (t + kWaves < t_end) load_frame(t + kWaves, vnext);   // prefetch: latency hides behind this frame's FFT
         process_frame(t, v);
     }
+#else
+    for (int t = t_begin + wave; t < t_end; t += kWaves) {
+        v2f v[16];
+        load_frame(t, v);
+        process_frame(t, v);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -353,7 +376,7 @@ template <int kMode>
 struct FinishShared {
     float fb[kMode == 0 ? kBins * kChroma + 4 : 4];   // chroma filterbank of the selected tuning, [bin][12]
     v2f peaks[kMode == 2 ? 1 : kPeakLdsCap];
-    unsigned hist[256];
+    unsigned hist[kMode == 2 ? 1 : 2048];
     float red[64];
     int ired[8];
     double lmean[kMels];
@@ -382,58 +405,94 @@ __device__ __forceinline__ void for_each_peak(const Sh& sh, bool in_lds, const S
     }
 }
 
-// k-th smallest peak magnitude (0-based) by 4-pass 8-bit radix select; all threads return it
+// k-th smallest peak magnitude (0-based) by radix select on the order-preserving key, 11 + 11 + 10
+// bits (wide digits keep the LDS histogram atomics spread: peak magnitudes share few exponents).
+// All threads return it.  blockDim.x must be 256.
 template <typename Sh>
 __device__ float select_kth(Sh& sh, bool in_lds, const Scratch& sc, const SegDesc& sd,
                             int peak_cap, unsigned k) {
     unsigned prefix = 0, mask = 0;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) sh.hist[i] = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+        const unsigned digit_mask = pass == 2 ? 1023u : 2047u;
+        for (int i = tid; i < 2048; i += 256) sh.hist[i] = 0;
         __syncthreads();
         for_each_peak(sh, in_lds, sc, sd, peak_cap, [&](v2f pm) {
             const unsigned key = float_key(pm.y);
-            if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+            if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & digit_mask], 1u);
         });
         __syncthreads();
-        if (threadIdx.x < 64) {
-            // one wave locates the bucket holding rank k: 4 bins per lane, inclusive scan over lanes
-            const int l = threadIdx.x;
-            const unsigned c0 = sh.hist[4 * l], c1 = sh.hist[4 * l + 1], c2 = sh.hist[4 * l + 2], c3 = sh.hist[4 * l + 3];
-            const unsigned mine = c0 + c1 + c2 + c3;
-            unsigned incl = mine;
+        // thread t owns buckets 8t..8t+7; block-wide inclusive scan of the per-thread totals
+        unsigned c[8];
+        unsigned mine = 0;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned up = __shfl_up(incl, o);
-                if (l >= o) incl += up;
-            }
-            const unsigned long long hit = __ballot(incl > k);
-            const int owner = hit ? __ffsll(static_cast<long long>(hit)) - 1 : 63;
-            if (l == owner) {
-                unsigned cum = incl - mine;
-                int b = 4 * l;
-                if (cum + c0 > k) {
-                } else if (cum + c0 + c1 > k) {
-                    cum += c0;
-                    b += 1;
-                } else if (cum + c0 + c1 + c2 > k) {
-                    cum += c0 + c1;
-                    b += 2;
-                } else {
-                    cum += c0 + c1 + c2;
-                    b += 3;
+        for (int j = 0; j < 8; ++j) {
+            c[j] = sh.hist[8 * tid + j];
+            mine += c[j];
+        }
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) sh.ired[wave] = static_cast<int>(incl);
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < wave; ++w) before += static_cast<unsigned>(sh.ired[w]);
+        incl += before;
+        const unsigned excl = incl - mine;
+        if (excl <= k && k < incl) {   // exactly one thread
+            unsigned cum = excl;
+            int b = 7;
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (!found) {
+                    if (cum + c[j] > k) {   // first bucket whose cumulative count exceeds k
+                        found = true;
+                        b = j;
+                    } else {
+                        cum += c[j];
+                    }
                 }
-                sh.sel_prefix = prefix | (static_cast<unsigned>(b) << shift);
-                sh.sel_k = k - cum;
             }
+            sh.sel_prefix = prefix | (static_cast<unsigned>(8 * tid + b) << shift);
+            sh.sel_k = k - cum;
         }
         __syncthreads();
         prefix = sh.sel_prefix;
         k = sh.sel_k;
-        mask |= 255u << shift;
-        __syncthreads();
+        mask |= digit_mask << shift;
     }
     return key_float(prefix);
+}
+
+// largest peak magnitude strictly below thr and how many there are (for the lower middle of an even count)
+template <typename Sh>
+__device__ void below_threshold(Sh& sh, bool in_lds, const Scratch& sc, const SegDesc& sd, int peak_cap,
+                                float thr, int* count, float* largest) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int n = 0;
+    float m = -INFINITY;
+    for_each_peak(sh, in_lds, sc, sd, peak_cap, [&](v2f pm) {
+        if (pm.y < thr) {
+            ++n;
+            m = fmaxf(m, pm.y);
+        }
+    });
+    n = wave_sum_int(n);
+    m = wave_max(m);
+    __syncthreads();   // sh.ired / sh.red free
+    if (lane == 0) {
+        sh.ired[wave] = n;
+        sh.red[wave] = m;
+    }
+    __syncthreads();
+    *count = sh.ired[0] + sh.ired[1] + sh.ired[2] + sh.ired[3];
+    *largest = fmaxf(fmaxf(sh.red[0], sh.red[1]), fmaxf(sh.red[2], sh.red[3]));
+    __syncthreads();
 }
 
 // on-the-fly chroma column for the generic path lives in kernels_generic.hpp
@@ -471,10 +530,18 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         // rounding of the exact value; a float32 running sum here would not be)
         double s = 0.0;
         float lmax = -INFINITY;
-        for (int t = half; t < sd.n_mel; t += 2) {
-            const float v = mel[static_cast<size_t>(t) * kMels + m];
-            s += static_cast<double>(v);
-            lmax = fmaxf(lmax, 10.0f * log10f(fmaxf(1e-10f, v)));
+        if constexpr (kMode == 2) {
+            // k_project_frames left dB values in `mel`, 16-frame power sums and per-tile dB maxima
+            const int n_tiles = (sd.n_mel + 15) >> 4;
+            const size_t tile0 = static_cast<size_t>(sd.mel_base) >> 4;
+            for (int tl = half; tl < n_tiles; tl += 2) s += static_cast<double>(sc.mel_part[(tile0 + tl) * kMels + m]);
+            for (int j = tid; j < n_tiles * 8; j += 256) lmax = fmaxf(lmax, sc.mel_dbmax[tile0 * 8 + j]);
+        } else {
+            for (int t = half; t < sd.n_mel; t += 2) {
+                const float v = mel[static_cast<size_t>(t) * kMels + m];
+                s += static_cast<double>(v);
+                lmax = fmaxf(lmax, 10.0f * log10f(fmaxf(1e-10f, v)));
+            }
         }
         sh.melsum[half][m] = s;
         lmax = wave_max(lmax);
@@ -486,7 +553,8 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         if (want_mfcc) {
             for (int t = half; t < sd.n_mel; t += 2) {
                 const float v = mel[static_cast<size_t>(t) * kMels + m];
-                ls += static_cast<double>(fmaxf(10.0f * log10f(fmaxf(1e-10f, v)), floor_db));
+                const float db = (kMode == 2) ? v : 10.0f * log10f(fmaxf(1e-10f, v));
+                ls += static_cast<double>(fmaxf(db, floor_db));
             }
         }
         sh.lsum[half][m] = ls;
@@ -558,7 +626,12 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
     if (n_peaks > 0) {
         float thr = select_kth(sh, in_lds, sc, sd, sc.peak_cap, static_cast<unsigned>(n_peaks / 2));
         if ((n_peaks & 1) == 0) {
-            const float lo = select_kth(sh, in_lds, sc, sd, sc.peak_cap, static_cast<unsigned>(n_peaks / 2 - 1));
+            // the element of rank n/2 - 1: the largest value below thr if exactly n/2 values are below it,
+            // else thr itself (a tie)
+            int n_below;
+            float below;
+            below_threshold(sh, in_lds, sc, sd, sc.peak_cap, thr, &n_below, &below);
+            const float lo = (n_below == n_peaks / 2) ? below : thr;
             thr = (lo + thr) / 2.0f;  // np.median of an even count: f32 mean of the middle pair
         }
         for (int i = tid; i < 256; i += blockDim.x) sh.hist[i] = 0;

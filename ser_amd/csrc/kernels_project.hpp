@@ -17,6 +17,10 @@
 
 #include "kernels_fast.hpp"
 
+#ifndef SERHIP_EXP
+#define SERHIP_EXP 0
+#endif
+
 namespace serhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -32,84 +36,158 @@ __device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 c) {
 
 // Mel blocks (16 filters each) are live over a contiguous run of groups [glo, ghi]; the runs advance
 // monotonically and at most two are live at once (serhip_plan_fast checks this), so the kernel keeps
-// two accumulator slots and retires the older one -- storing its 32 x 16 tile -- when its run ends.
+// two accumulator slots ("lo" = oldest live block, "hi" = the next) and retires the older one --
+// storing its 32 x 16 tile -- when its run ends.  The host compiles this into a per-group program
+// (PlanTables::mel_prog): which B rows the two slots use (row 0 is all zeros), which slots are live,
+// and how many blocks retire after the group.  All operands of group G + 1 are requested before the
+// MFMAs of group G are issued.
 __global__ __launch_bounds__(256) void k_project_frames(const SegDesc* __restrict__ segs, PlanTables tb, Scratch sc) {
+    // B rows of the current and the next group, shared by the four waves (all work on one segment, so on
+    // one tuning): [stage][0 chroma | 1 mel slot lo | 2 mel slot hi][lane]
+    __shared__ float4 s_b[2][3][64];
+    __shared__ int4 s_prog[kGroups];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const SegDesc sd = segs[blockIdx.y];
+    if (blockIdx.x * 4 * kProjTile >= sd.n_stft) return;   // whole workgroup
     const int t0 = (blockIdx.x * 4 + wave) * kProjTile;
-    if (t0 >= sd.n_stft) return;   // no workgroup barrier in this kernel: waves leave independently
+    const bool active = t0 < sd.n_stft;   // a wave without a tile still fetches B rows and joins the barriers
     const bool want_chroma = (tb.flags & 2u) != 0, want_mel = (tb.flags & 5u) != 0;
     const int i = lane & 15, kk = lane >> 4;
-    const int last = sd.n_stft - 1;
-    const float* a0p = sc.mags + (static_cast<size_t>(sd.stft_base) + min(t0 + i, last)) * kBinStride + 4 * kk;
-    const float* a1p = sc.mags + (static_cast<size_t>(sd.stft_base) + min(t0 + 16 + i, last)) * kBinStride + 4 * kk;
+    // A operands: the two 16-frame tiles of this wave; group G of a tile is the 1 KB block at float4
+    // index G*64 and lane (frame i, kk) takes float4 i*4 + kk of it (one fully coalesced 1 KB read).  Frame
+    // slots past the segment's end inside a tile were never written: their rows of C are garbage and are
+    // not stored.  A second tile that lies wholly past the end is replaced by the first; a wave without a
+    // tile reads the workgroup's first tile and discards it.  Every wave issues the same three loads per
+    // group, unconditionally: the waits in the loop are then exact vmcnt(n) counts and the prefetch holds.
+    const size_t f0 = static_cast<size_t>(sd.stft_base) + (active ? t0 : blockIdx.x * 4 * kProjTile);
+    const float4* a0p = reinterpret_cast<const float4*>(sc.mags) + (f0 >> 4) * kGroups * 64 + i * 4 + kk;
+    const float4* a1p = (active && t0 + 16 < sd.n_stft) ? a0p + kGroups * 64 : a0p;
     const float4* cb = tb.chroma_b + (want_chroma ? static_cast<size_t>(sc.tuning_idx[blockIdx.y]) * kGroups * 64 : 0) + lane;
     const float4* mb = tb.mel_b + lane;
     float* mel_out = sc.mel + (static_cast<size_t>(sd.mel_base) + t0 + 4 * kk) * kMels + i;
 
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
     f32x4 c0 = zero, c1 = zero;
-    f32x4 lo0 = zero, lo1 = zero, hi0 = zero, hi1 = zero;   // mel blocks cur and cur + 1
-    int cur = 0;
-    int4 blk_lo = tb.mel_blk[0], blk_hi = tb.mel_blk[1];     // {glo, ghi, table offset, 0}
+    f32x4 lo0 = zero, lo1 = zero, hi0 = zero, hi1 = zero;
+    int cur = 0;   // block held by slot lo
 
-    // store the retiring block's tile: C layout = column j = lane & 15 (filter), rows 4*kk + r (frames)
-    auto retire = [&](int b, const f32x4& v0, const f32x4& v1) {
+    // Retire slot lo (block cur).  C layout: column j = lane & 15 (filter), rows 4*kk + r (frames).  Per
+    // 16-frame half tile it leaves what k_segment_finish<2> reduces: the power in dB per frame
+    // (power_to_db of mfcc, dsp.py:108), the power summed over the tile's frames (mel mean) and the
+    // tile's largest dB value (top_db reference).  Sums run in a fixed order: results do not depend on
+    // what else is in the batch.
+    auto retire = [&]() {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (t0 + 4 * kk + r < sd.n_stft) mel_out[static_cast<size_t>(r) * kMels + 16 * b] = v0[r];
-            if (t0 + 16 + 4 * kk + r < sd.n_stft) mel_out[static_cast<size_t>(16 + r) * kMels + 16 * b] = v1[r];
+        for (int h = 0; h < 2; ++h) {
+            const int tb0 = t0 + 16 * h;
+            if (tb0 < sd.n_stft) {   // wave-uniform
+                const f32x4 v = h ? lo1 : lo0;
+                float psum = 0.0f, dmax = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (tb0 + 4 * kk + r < sd.n_stft) {
+                        const float db = 10.0f * log10f(fmaxf(1e-10f, v[r]));
+                        psum += v[r];
+                        dmax = fmaxf(dmax, db);
+                        mel_out[static_cast<size_t>(16 * h + r) * kMels + 16 * cur] = db;
+                    }
+                }
+                psum += __shfl_xor(psum, 16);
+                psum += __shfl_xor(psum, 32);
+                dmax = wave_max(dmax);
+                const size_t tile = (f0 >> 4) + h;
+                if (kk == 0) sc.mel_part[tile * kMels + 16 * cur + i] = psum;
+                if (lane == 0) sc.mel_dbmax[tile * 8 + cur] = dmax;
+            }
+        }
+        lo0 = hi0;
+        lo1 = hi1;
+        hi0 = hi1 = zero;
+        ++cur;
+    };
+    // wave w fetches B row w of a group (0 chroma, 1 mel slot lo, 2 mel slot hi).  A wave with nothing to
+    // fetch (wave 3, an idle mel slot, chroma off) still loads a row some other wave of this group needs
+    // -- never the shared all-zero row 0, which every workgroup on the chip would hammer in L2.
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto fetch_b = [&](int G, const int4& p) {
+        const int live = want_mel ? p.z : 0;
+        const float4* fallback = want_chroma ? cb + G * 64 : mb + static_cast<size_t>(max(p.x, p.y)) * 64;
+        const float4* row = fallback;
+        if (wave_s == 1 && (live & 1)) row = mb + static_cast<size_t>(p.x) * 64;
+        if (wave_s == 2 && (live & 2)) row = mb + static_cast<size_t>(p.y) * 64;
+        return *row;
+    };
+    // the per-group program, read as scalars (a vector load here would put a full vmcnt(0) wait, and
+    // with it the end of all prefetching, into every iteration)
+    auto prog_at = [&](int G) {
+        const int4 v = s_prog[G];
+        return int4{__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                    __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w)};
+    };
+    // MFMAs of one group; B rows come from LDS stage G & 1
+    auto compute = [&](int G, const float4& a0, const float4& a1, const int4& p) {
+        if (!active) return;
+        const float4* sb = &s_b[G & 1][0][lane];
+        if (want_chroma) {
+            const float4 bc = sb[0];
+            c0 = mfma4(a0, bc, c0);
+            c1 = mfma4(a1, bc, c1);
+        }
+        if (want_mel) {
+            const float4 p0 = float4{a0.x * a0.x, a0.y * a0.y, a0.z * a0.z, a0.w * a0.w};   // |X|^2 of the rounded |X|
+            const float4 p1 = float4{a1.x * a1.x, a1.y * a1.y, a1.z * a1.z, a1.w * a1.w};
+            if (p.z & 1) {   // wave-uniform
+                const float4 bl = sb[64];
+                lo0 = mfma4(p0, bl, lo0);
+                lo1 = mfma4(p1, bl, lo1);
+            }
+            if (p.z & 2) {
+                const float4 bh = sb[128];
+                hi0 = mfma4(p0, bh, hi0);
+                hi1 = mfma4(p1, bh, hi1);
+            }
+            for (int n = p.w; n > 0; --n) retire();
         }
     };
 
+    // Software pipeline over two register sets (E for even groups, O for odd), no register copies:
+    // step G requests the B row of G + 2 first, multiplies group G, stores the B row of G + 1 (requested
+    // a step ago) to LDS and then requests the A rows of G + 2.
+    for (int j = threadIdx.x; j < kGroups; j += 256) s_prog[j] = tb.mel_prog[j];
+    float4 aE0 = a0p[0], aE1 = a1p[0], aO0 = a0p[64], aO1 = a1p[64];
+    __syncthreads();
+    float4 bE = fetch_b(0, prog_at(0));
+    float4 bO = fetch_b(1, prog_at(1));
+    if (wave < 3) s_b[0][wave][lane] = bE;
+    __syncthreads();
+
 #pragma unroll 1
-    for (int G = 0; G < kGroups; ++G) {
-        // group 64 holds only bin 1024 (+ three zero pads): lanes kk > 0 re-read the kk = 0 chunk and
-        // zero it, so no load leaves the row
-        const bool tail = (G == kGroups - 1);
-        const int aoff = 16 * G - (tail ? 4 * kk : 0);
-        float4 a0 = *reinterpret_cast<const float4*>(a0p + aoff);
-        float4 a1 = *reinterpret_cast<const float4*>(a1p + aoff);
-        if (tail && kk != 0) a0 = a1 = float4{0.f, 0.f, 0.f, 0.f};
-        if (want_chroma) {
-            const float4 b = cb[G * 64];
-            c0 = mfma4(a0, b, c0);
-            c1 = mfma4(a1, b, c1);
-        }
-        if (want_mel) {
-            while (cur < 8 && G > blk_lo.y) {   // wave-uniform
-                retire(cur, lo0, lo1);
-                lo0 = hi0;
-                lo1 = hi1;
-                hi0 = hi1 = zero;
-                ++cur;
-                blk_lo = blk_hi;
-                blk_hi = tb.mel_blk[min(cur + 1, 8)];   // entry 8 is a sentinel that never starts
-            }
-            const float4 p0 = float4{a0.x * a0.x, a0.y * a0.y, a0.z * a0.z, a0.w * a0.w};   // |X|^2 of the rounded |X|
-            const float4 p1 = float4{a1.x * a1.x, a1.y * a1.y, a1.z * a1.z, a1.w * a1.w};
-            if (cur < 8 && G >= blk_lo.x) {
-                const float4 w = mb[static_cast<size_t>(blk_lo.z + G - blk_lo.x) * 64];
-                lo0 = mfma4(p0, w, lo0);
-                lo1 = mfma4(p1, w, lo1);
-            }
-            if (cur < 7 && G >= blk_hi.x) {
-                const float4 w = mb[static_cast<size_t>(blk_hi.z + G - blk_hi.x) * 64];
-                hi0 = mfma4(p0, w, hi0);
-                hi1 = mfma4(p1, w, hi1);
-            }
-        }
+    for (int G = 0; G < kGroups - 1; G += 2) {
+        // even group G: stage 0 holds its B rows
+        bE = fetch_b(G + 2, prog_at(G + 2));            // G + 2 <= 64
+        compute(G, aE0, aE1, prog_at(G));
+        if (wave < 3) s_b[1][wave][lane] = bO;          // B rows of G + 1
+        aE0 = a0p[(G + 2) * 64];
+        aE1 = a1p[(G + 2) * 64];
+        __syncthreads();
+        // odd group G + 1: stage 1
+        const int G3 = min(G + 3, kGroups - 1);         // the last odd step re-reads group 64 (unused)
+        bO = fetch_b(G3, prog_at(G3));
+        compute(G + 1, aO0, aO1, prog_at(G + 1));
+        if (wave < 3) s_b[0][wave][lane] = bE;          // B rows of G + 2
+        aO0 = a0p[G3 * 64];
+        aO1 = a1p[G3 * 64];
+        __syncthreads();
     }
-    if (want_mel) {
-        while (cur < 8) {
-            retire(cur, lo0, lo1);
-            lo0 = hi0;
-            lo1 = hi1;
-            hi0 = hi1 = zero;
-            ++cur;
-        }
-    }
+    // group 64 (kGroups is odd) holds only bin 1024 and three zero pads, in the kk = 0 chunk; the other
+    // chunks of that 1 KB block were never written
+    if (kk != 0) aE0 = aE1 = zero4;
+    compute(kGroups - 1, aE0, aE1, prog_at(kGroups - 1));
+    if (active && want_mel)
+        while (cur < 8) retire();
+    if (!active) return;
 
     // ---- chroma epilogue: per-frame inf-norm over the 16 lanes that hold one frame's classes
     if (want_chroma) {

@@ -83,7 +83,7 @@ void build_host_tables(int sr, HostTables& h, bool with_chroma) {
     // B operands of k_project_frames: lane (kk = lane>>4, j = lane&15) of group G holds the weights of
     // filter/class j for bins 16G + 4kk + u, u = 0..3.  Block b = filters 16b..16b+15 keeps only the
     // contiguous run of groups in which one of its filters is nonzero (the Slaney bank is banded).
-    h.mel_b.clear();
+    h.mel_b.assign(256, 0.0f);   // row 0: zeros, the operand of an idle accumulator slot
     for (int b = 0; b < 8; ++b) {
         int glo = -1, ghi = -1;
         for (int m = 16 * b; m < 16 * b + 16; ++m)
@@ -201,13 +201,15 @@ int ensure_staging(serhip_ctx* ctx, size_t bytes) {
 }
 
 struct ScratchLayout {
-    size_t mags, mel, peaks, cnt, cnorm, tidx, total;
+    size_t mags, mel, peaks, cnt, cnorm, tidx, mpart, mdbmax, total;
 };
 ScratchLayout scratch_layout(size_t frames, int peak_cap, size_t segs) {
     ScratchLayout l{};
     size_t o = 0;
     l.mags = o;
-    o = align_up(o + frames * kBinStride * sizeof(float), 256);
+    // rows of kBinStride floats (generic path) or 16-frame tiles of kTileBytes (fast path; frames is a
+    // multiple of 16 there)
+    o = align_up(o + std::max(frames * kBinStride * sizeof(float), (frames + 15) / 16 * static_cast<size_t>(kTileBytes)), 256);
     l.mel = o;
     o = align_up(o + frames * kMels * sizeof(float), 256);
     l.peaks = o;
@@ -218,6 +220,10 @@ ScratchLayout scratch_layout(size_t frames, int peak_cap, size_t segs) {
     o = align_up(o + frames * 16 * sizeof(float), 256);
     l.tidx = o;
     o = align_up(o + segs * sizeof(int), 256);
+    l.mpart = o;
+    o = align_up(o + (frames + 15) / 16 * kMels * sizeof(float), 256);
+    l.mdbmax = o;
+    o = align_up(o + (frames + 15) / 16 * 8 * sizeof(float), 256);
     l.total = o;
     return l;
 }
@@ -229,6 +235,8 @@ Scratch scratch_at(char* base, const ScratchLayout& l, int peak_cap) {
     s.peak_cnt = reinterpret_cast<int*>(base + l.cnt);
     s.chroma_norm = reinterpret_cast<float*>(base + l.cnorm);
     s.tuning_idx = reinterpret_cast<int*>(base + l.tidx);
+    s.mel_part = reinterpret_cast<float*>(base + l.mpart);
+    s.mel_dbmax = reinterpret_cast<float*>(base + l.mdbmax);
     s.peak_cap = peak_cap;
     return s;
 }
@@ -415,9 +423,6 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
 
     // k_project_frames keeps two mel blocks live at a time: runs must advance monotonically and block
     // b + 2 must start after block b ends (true for the Slaney bank at any practical sample rate)
-    int4 blk[9];
-    for (int b = 0; b < 8; ++b) blk[b] = int4{h.mel_glo[b], h.mel_ghi[b], h.mel_off[b], 0};
-    blk[8] = int4{0x7fffffff, 0x7fffffff, 0, 0};
     if (feature_flags & (SERHIP_FEAT_MFCC | SERHIP_FEAT_MEL))
         for (int b = 0; b < 8; ++b) {
             const bool bad = h.mel_glo[b] > h.mel_ghi[b] || (b > 0 && (h.mel_glo[b] < h.mel_glo[b - 1] || h.mel_ghi[b] < h.mel_ghi[b - 1])) ||
@@ -427,6 +432,27 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
                             "serhip_plan_fast: mel filterbank layout at this sample rate is not supported (filter block " +
                                 std::to_string(b) + ")");
         }
+    // the per-group program of k_project_frames (see kernels_project.hpp)
+    int4 prog[kGroups];
+    {
+        int cur = 0;
+        for (int G = 0; G < kGroups; ++G) {
+            int4 e{0, 0, 0, 0};
+            if (cur < 8 && G >= h.mel_glo[cur] && G <= h.mel_ghi[cur]) {
+                e.x = h.mel_off[cur] + G - h.mel_glo[cur];
+                e.z |= 1;
+            }
+            if (cur + 1 < 8 && G >= h.mel_glo[cur + 1] && G <= h.mel_ghi[cur + 1]) {
+                e.y = h.mel_off[cur + 1] + G - h.mel_glo[cur + 1];
+                e.z |= 2;
+            }
+            while (cur < 8 && h.mel_ghi[cur] <= G) {
+                ++e.w;
+                ++cur;
+            }
+            prog[G] = e;
+        }
+    }
 
     // one device blob, sub-allocated
     size_t o = 0;
@@ -437,7 +463,7 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
     };
     const size_t o_twA = take(h.twA.size() * sizeof(v2f)), o_twB = take(h.twB.size() * sizeof(v2f)),
                  o_twU = take(h.twU.size() * sizeof(v2f)), o_win = take(h.win.size() * sizeof(v2f)),
-                 o_melb = take(std::max<size_t>(h.mel_b.size(), 4) * sizeof(float)), o_blk = take(9 * sizeof(int4)),
+                 o_melb = take(std::max<size_t>(h.mel_b.size(), 4) * sizeof(float)), o_blk = take(sizeof(prog)),
                  o_chroma = take(std::max<size_t>(h.chroma_b.size(), 4) * sizeof(float)),
                  o_dct = take(h.dct.size() * sizeof(float)), o_edges = take(h.edges.size() * sizeof(double)),
                  o_melf = take(h.mel_f.size() * sizeof(double));
@@ -450,7 +476,7 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
     put(o_twU, h.twU.data(), h.twU.size() * sizeof(v2f));
     put(o_win, h.win.data(), h.win.size() * sizeof(v2f));
     put(o_melb, h.mel_b.data(), h.mel_b.size() * sizeof(float));
-    put(o_blk, blk, sizeof(blk));
+    put(o_blk, prog, sizeof(prog));
     put(o_chroma, h.chroma_b.data(), h.chroma_b.size() * sizeof(float));
     put(o_dct, h.dct.data(), h.dct.size() * sizeof(float));
     put(o_edges, h.edges.data(), h.edges.size() * sizeof(double));
@@ -478,7 +504,7 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
     tb.win = reinterpret_cast<const v2f*>(d + o_win);
     tb.mel_b = reinterpret_cast<const float4*>(d + o_melb);
     tb.chroma_b = reinterpret_cast<const float4*>(d + o_chroma);
-    tb.mel_blk = reinterpret_cast<const int4*>(d + o_blk);
+    tb.mel_prog = reinterpret_cast<const int4*>(d + o_blk);
     tb.dct = reinterpret_cast<const float*>(d + o_dct);
     tb.edges = reinterpret_cast<const double*>(d + o_edges);
     tb.mel_f = reinterpret_cast<const double*>(d + o_melf);
@@ -549,7 +575,7 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
         if (np >= kNfft) {
             d.n_fft = kNfft;
             d.n_stft = d.n_mel = static_cast<int>(1 + np / kHop);
-            const size_t fr = static_cast<size_t>(d.n_stft);
+            const size_t fr = (static_cast<size_t>(d.n_stft) + 15) / 16 * 16;   // segments start on a 16-frame tile
             if (cur.count > 0 && (cur_frames + fr > chunk_cap || cur.count >= 65535)) {
                 chunks.push_back(cur);
                 max_chunk_frames = std::max(max_chunk_frames, cur_frames);
