@@ -22,7 +22,8 @@ namespace serhip {
 #define SERHIP_K1_WAVES 16
 #endif
 #ifndef SERHIP_K1_PREFETCH
-#define SERHIP_K1_PREFETCH 0   // 1: keep the next frame's samples in 32 more VGPRs (pays only below 16 waves)
+#define SERHIP_K1_PREFETCH 0   // 1: request the next frame's samples before this frame's unpack / stores / peaks
+                               // (needs > 128 VGPRs: measured no faster at 12 waves, spills at 16)
 #endif
 // k_stft_frames runs ONE workgroup per CU: its waves share the 21 KB of twiddle/window tables in LDS and
 // each owns an 8.5 KB transpose buffer.  16 waves = 4 per SIMD at <= 128 VGPRs fill the 160 KB of LDS;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     };
     const v2f rot3 = (q == 3) ? v2f{0.0f, -1.0f} : v2f{1.0f, 0.0f};   // lane 3 of a quad turns by -i
     // one frame, consumed from v (the raw sample pairs loaded by load_frame)
-    auto process_frame = [&](int t, v2f (&v)[16]) {
+    auto transform_frame = [&](v2f (&v)[16]) {
         // s_win holds HALF the Hann window: the FFT is linear and halving is exact, so the unpack below
         // needs no 0.5 factors
 #pragma unroll
@@ -237,7 +238,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             buf[k1b + 16 * j1 + 260 * j2] = w;
         }
         wave_lds_sync();
-
+    };
+    // second half of a frame: Z (in this wave's LDS buffer) -> |X|, stores, peaks.  Needs no registers
+    // of the transform, so the next frame's samples are requested before it starts.
+    auto finish_frame = [&](int t) {
         // ---- real-FFT unpack: bins k = lane + 64r and 1024 - k from Z[k], Z[1024-k]
         float mlo[8], mhi[8];
 #pragma unroll
@@ -319,23 +323,21 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
     };
 
+    // The samples of frame t + kWaves are loaded into the registers frame t's transform has just
+    // released, ahead of frame t's stores: the loads are older than the stores in the vmcnt queue, so
+    // the next transform waits for its samples only, not for the write-back of this frame.
+    v2f v[16];
+    if (t_begin + wave < t_end) load_frame(t_begin + wave, v);
+    for (int t = t_begin + wave; t < t_end; t += kWaves) {
+        transform_frame(v);
 #if SERHIP_K1_PREFETCH
-    v2f vnext[16];
-    if (t_begin + wave < t_end) load_frame(t_begin + wave, vnext);
-    for (int t = t_begin + wave; t < t_end; t += kWaves) {
-        v2f v[16];
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = vnext[n1];
-        if (t + kWaves < t_end) load_frame(t + kWaves, vnext);   // prefetch: latency hides behind this frame's FFT
-        process_frame(t, v);
-    }
+        load_frame(min(t + kWaves, t_end - 1), v);   // unconditional (the last one is a harmless re-read)
+        finish_frame(t);
 #else
-    for (int t = t_begin + wave; t < t_end; t += kWaves) {
-        v2f v[16];
-        load_frame(t, v);
-        process_frame(t, v);
-    }
+        finish_frame(t);
+        if (t + kWaves < t_end) load_frame(t + kWaves, v);
 #endif
+    }
 }
 
 // ---------------------------------------------------------------------------------------
