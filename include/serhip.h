@@ -116,6 +116,26 @@ int serhip_pool_windows(serhip_ctx* ctx, const float* emb_dev, int32_t n_frames,
 int serhip_whisper_logmel(serhip_ctx* ctx, const float* audio_dev, int32_t n_clips,
                           int64_t n_samples, int32_t n_mels, float* out_dev, void* stream);
 
+/* Device-side audio preparation: replaces _prepare_audio_buffer / _to_mono / _normalize_audio
+ * (ser/_internal/utils/audio_utils.py:28-60) and the sample conversion libsndfile does inside
+ * librosa.load (audio_utils.py:104-109) for a batch of decoded-but-raw clips, so that the host
+ * only parses file headers and copies payload bytes.
+ *   raw_dev        device, the interleaved sample payloads of the clips (any layout; see offsets)
+ *   sample_format  SERHIP_SAMPLE_S16 (little-endian PCM16, value / 32768) or SERHIP_SAMPLE_F32
+ *   clip_raw_offset host, byte offset of each clip's first frame in raw_dev (multiple of the
+ *                  sample size), clip_frames host, sample frames per clip (>= 1),
+ *   clip_channels  host, channels per clip (1..64), clip_out_offset host, first output sample
+ *   out_dev        device f32: per clip `frames` mono samples: non-finite -> 0, float32 channel
+ *                  mean (numpy summation order), divided by the clip's max |x| (all-zero stays 0)
+ * Results are bit-identical to the numpy reference code.  Every clip must lie inside
+ * [0, raw_bytes) and [0, out_samples). */
+#define SERHIP_SAMPLE_S16 0
+#define SERHIP_SAMPLE_F32 1
+int serhip_prepare_audio(serhip_ctx* ctx, const void* raw_dev, int64_t raw_bytes, int sample_format,
+                         const int64_t* clip_raw_offset, const int64_t* clip_frames,
+                         const int32_t* clip_channels, const int64_t* clip_out_offset, int64_t n_clips,
+                         float* out_dev, int64_t out_samples, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on.
  * No reference counterpart (the reference's only timer is the phase stopwatch of
  * ser/_internal/runtime/phase_timing.py:29-78 around whole inferences); bench.py uses

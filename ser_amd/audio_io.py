@@ -16,6 +16,7 @@ import logging
 import struct
 import time
 from pathlib import Path
+from typing import NamedTuple
 
 import numpy as np
 from numpy.typing import NDArray
@@ -95,6 +96,71 @@ def _parse_wave(data: bytes):
     if channels > 1:
         x = x.reshape(-1, channels)
     return x, int(rate)
+
+
+class RawClip(NamedTuple):
+    """Undecoded sample payload of one file (or segment), for ``FeatureEngine.prepare_audio``."""
+
+    payload: memoryview      # interleaved little-endian samples, `frames * channels` of them
+    sample_format: str       # "s16" | "f32"
+    channels: int
+    frames: int
+    sample_rate: int
+
+
+def read_raw_clip(file_path: str, *, start_seconds: float | None = None,
+                  duration_seconds: float | None = None) -> RawClip | None:
+    """Header-only read for device-side preparation: PCM16 and float32 RIFF/WAVE payloads are
+    returned as bytes (no conversion, no normalisation on the host).  Returns None for encodings
+    that need a host decode (8/24/32-bit PCM, float64): callers then use :func:`read_audio_file`.
+    File-level errors are the same as :func:`read_audio_file`'s."""
+    if start_seconds is not None and start_seconds < 0.0:
+        raise ValueError("start_seconds must be >= 0")
+    if duration_seconds is not None and duration_seconds <= 0.0:
+        raise ValueError("duration_seconds must be > 0")
+    path = Path(file_path)
+    if not path.exists():
+        raise FileNotFoundError(f"Audio file not found: {file_path}")
+    if not path.is_file():
+        raise OSError(f"Path is not a regular file: {file_path}")
+    data = path.read_bytes()
+    if data.startswith(_GIT_LFS_POINTER_PREFIX):
+        raise AudioIntegrityError(
+            f"Audio file is an unmaterialized Git LFS pointer: {file_path}. "
+            "Install Git LFS, then run `git lfs pull` and `git lfs checkout` "
+            "in the dataset checkout."
+        )
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise AudioDecodeError(f"Error reading {file_path}")
+    pos, fmt, body_at, body_len = 12, None, -1, 0
+    while pos + 8 <= len(data):
+        tag, size = data[pos : pos + 4], struct.unpack_from("<I", data, pos + 4)[0]
+        if tag == b"fmt ":
+            fmt = data[pos + 8 : pos + 8 + size]
+        elif tag == b"data":
+            body_at, body_len = pos + 8, min(size, len(data) - pos - 8)
+        pos += 8 + size + (size & 1)
+    if fmt is None or body_at < 0 or len(fmt) < 16:
+        raise AudioDecodeError(f"Error reading {file_path}")
+    code, channels, rate, _, block_align, bits = struct.unpack_from("<HHIIHH", fmt, 0)
+    if code == 0xFFFE and len(fmt) >= 26:
+        code = struct.unpack_from("<H", fmt, 24)[0]
+    if channels == 0 or rate == 0 or block_align == 0:
+        raise AudioDecodeError(f"Error reading {file_path}")
+    if code == 1 and bits == 16 and block_align == 2 * channels:
+        sample_format = "s16"
+    elif code == 3 and bits == 32 and block_align == 4 * channels:
+        sample_format = "f32"
+    else:
+        return None
+    if channels > 64:
+        return None
+    n_frames = body_len // block_align
+    first = int(float(start_seconds or 0.0) * rate)
+    last = n_frames if duration_seconds is None else min(n_frames, first + int(float(duration_seconds) * rate))
+    first = min(first, n_frames)
+    view = memoryview(data)[body_at + first * block_align : body_at + max(first, last) * block_align]
+    return RawClip(view, sample_format, int(channels), max(0, last - first), int(rate))
 
 
 def decode_file(path: Path, *, start_seconds: float = 0.0, duration_seconds: float | None = None):

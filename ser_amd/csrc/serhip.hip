@@ -14,6 +14,7 @@
 
 #include "kernels_fast.hpp"
 #include "kernels_generic.hpp"
+#include "kernels_prepare.hpp"
 #include "kernels_project.hpp"
 #include "kernels_whisper.hpp"
 #include "tables.hpp"
@@ -736,6 +737,62 @@ int serhip_whisper_logmel(serhip_ctx* ctx, const float* audio_dev, int32_t n_cli
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     HIP_TRY(hipSetDevice(ctx->device));
     return whisper_logmel_launch(ctx, audio_dev, n_clips, n_samples, n_mels, out_dev, stream);
+}
+
+int serhip_prepare_audio(serhip_ctx* ctx, const void* raw_dev, int64_t raw_bytes, int sample_format,
+                         const int64_t* clip_raw_offset, const int64_t* clip_frames, const int32_t* clip_channels,
+                         const int64_t* clip_out_offset, int64_t n_clips, float* out_dev, int64_t out_samples,
+                         void* stream_v) {
+    if (!ctx) return fail(SERHIP_E_INVALID, "serhip_prepare_audio: ctx is NULL");
+    if (n_clips < 0) return fail(SERHIP_E_INVALID, "serhip_prepare_audio: n_clips < 0");
+    if (n_clips == 0) return SERHIP_OK;
+    if (!raw_dev || !clip_raw_offset || !clip_frames || !clip_channels || !clip_out_offset || !out_dev)
+        return fail(SERHIP_E_INVALID, "serhip_prepare_audio: NULL buffer");
+    if (sample_format != SERHIP_SAMPLE_S16 && sample_format != SERHIP_SAMPLE_F32)
+        return fail(SERHIP_E_INVALID, "serhip_prepare_audio: unknown sample format");
+    const int64_t ssize = sample_format == SERHIP_SAMPLE_S16 ? 2 : 4;
+    std::vector<PrepClip> clips(static_cast<size_t>(n_clips));
+    int64_t max_frames = 0;
+    for (int64_t i = 0; i < n_clips; ++i) {
+        const int64_t off = clip_raw_offset[i], fr = clip_frames[i], ch = clip_channels[i], oo = clip_out_offset[i];
+        if (fr < 1 || ch < 1 || ch > 64)
+            return fail(SERHIP_E_INVALID, "serhip_prepare_audio: clip " + std::to_string(i) + " has no frames or a bad channel count");
+        if (off < 0 || off % ssize != 0 || fr > (raw_bytes - off) / (ssize * ch) || oo < 0 || fr > out_samples - oo)
+            return fail(SERHIP_E_INVALID, "serhip_prepare_audio: clip " + std::to_string(i) + " lies outside the buffers");
+        clips[static_cast<size_t>(i)] = PrepClip{off, oo, fr, static_cast<int>(ch), 0};
+        max_frames = std::max(max_frames, fr);
+    }
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t desc_bytes = align_up(clips.size() * sizeof(PrepClip), 256);
+    const size_t peak_bytes = align_up(clips.size() * sizeof(unsigned), 256);
+    int rc = ensure_workspace(ctx, desc_bytes + peak_bytes);
+    if (rc != SERHIP_OK) return rc;
+    rc = ensure_staging(ctx, clips.size() * sizeof(PrepClip));
+    if (rc != SERHIP_OK) return rc;
+    std::memcpy(ctx->staging, clips.data(), clips.size() * sizeof(PrepClip));
+    PrepClip* d_clips = reinterpret_cast<PrepClip*>(ctx->ws);
+    unsigned* d_peak = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->ws) + desc_bytes);
+    HIP_TRY(hipMemcpyAsync(d_clips, ctx->staging, clips.size() * sizeof(PrepClip), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(ctx->staging_done, stream));
+    HIP_TRY(hipMemsetAsync(d_peak, 0, clips.size() * sizeof(unsigned), stream));
+    const unsigned char* raw = static_cast<const unsigned char*>(raw_dev);
+    // enough workgroups per clip for ~4 frames per thread, bounded so that many short clips still
+    // launch one modest grid
+    const unsigned gx = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((max_frames + 1023) / 1024, 1024)));
+    for (int64_t first = 0; first < n_clips; first += 65535) {
+        const unsigned gy = static_cast<unsigned>(std::min<int64_t>(65535, n_clips - first));
+        if (sample_format == SERHIP_SAMPLE_S16)
+            hipLaunchKernelGGL(k_prepare_convert<0>, dim3(gx, gy), dim3(256), 0, stream, raw, d_clips + first, out_dev,
+                               d_peak + first);
+        else
+            hipLaunchKernelGGL(k_prepare_convert<1>, dim3(gx, gy), dim3(256), 0, stream, raw, d_clips + first, out_dev,
+                               d_peak + first);
+        hipLaunchKernelGGL(k_prepare_normalise, dim3(gx, gy), dim3(256), 0, stream, d_clips + first, out_dev,
+                           d_peak + first);
+    }
+    HIP_TRY(hipGetLastError());
+    return SERHIP_OK;
 }
 
 int serhip_profile_enable(serhip_ctx* ctx, int on) {

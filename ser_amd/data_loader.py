@@ -30,7 +30,7 @@ from typing import NamedTuple
 import numpy as np
 from numpy.typing import NDArray
 
-from .audio_io import read_audio_file
+from .audio_io import AudioIntegrityError, read_audio_file, read_raw_clip
 from .handcrafted import HandcraftedBackend
 from .types import FAST_PATH_FLAGS, AudioReadConfig, FeatureFlags
 
@@ -129,43 +129,90 @@ def process_file(file: str, observed_emotions: Collection[str], emotion_map: Map
 
 
 def _read_one(job):
-    path, start, duration, config = job
+    """Read one job.  Returns ``(kind, value, error)``: kind "raw" (a RawClip whose samples the GPU
+    converts and normalises), "host" (``(samples, rate)`` decoded and prepared on the host: encodings
+    the device path does not take) or None with the error."""
+    path, start, duration, config, device_prepare = job
     try:
-        return read_audio_file(path, start_seconds=start, duration_seconds=duration, audio_read_config=config), None
+        if device_prepare:
+            try:
+                raw = read_raw_clip(path, start_seconds=start, duration_seconds=duration)
+            except (FileNotFoundError, AudioIntegrityError, ValueError):
+                raise
+            except Exception:
+                raw = None   # let the host reader produce the reference's retries and error
+            if raw is not None and raw.frames > 0:
+                return "raw", raw, None
+        return "host", read_audio_file(path, start_seconds=start, duration_seconds=duration,
+                                       audio_read_config=config), None
     except Exception as err:  # counted per file by the caller, like the reference
-        return None, err
+        return None, None, err
+
+
+def _featurize_raw_group(clips, rate: int, sample_format: str, feature_flags: FeatureFlags):
+    """One GPU batch for raw clips of one (sample rate, sample format): payload bytes are packed
+    back to back (16-byte aligned), converted / mixed down / peak-normalised on the device
+    (``serhip_prepare_audio``) and featurised from there -- the samples never exist on the host."""
+    from . import dsp
+    from .engine import get_engine
+
+    dsp.check_flags_for_rate(feature_flags, rate)
+    offsets, cursor = [], 0
+    for clip in clips:
+        offsets.append(cursor)
+        cursor += (len(clip.payload) + 15) // 16 * 16
+    packed = np.zeros(cursor, dtype=np.uint8)
+    for clip, at in zip(clips, offsets):
+        packed[at : at + len(clip.payload)] = np.frombuffer(clip.payload, dtype=np.uint8)
+    engine = get_engine()
+    audio, out_off, frames = engine.prepare_audio(packed, sample_format, offsets, [c.frames for c in clips],
+                                                  [c.channels for c in clips])
+    return engine.features(audio, out_off, frames, rate, feature_flags).cpu().numpy().astype(np.float64)
 
 
 def featurize_audio_jobs(jobs: Sequence[tuple[str, float | None, float | None]], *, feature_flags: FeatureFlags,
-                         audio_read_config: AudioReadConfig, workers: int = 8):
-    """Decode ``(path, start_seconds, duration_seconds)`` jobs on host threads and featurise every
-    readable clip in one GPU batch per sample rate.
+                         audio_read_config: AudioReadConfig, workers: int = 8, device_prepare: bool = True):
+    """Read ``(path, start_seconds, duration_seconds)`` jobs on host threads and featurise every
+    readable clip in one GPU batch per (sample rate, sample format).
 
-    Returns ``(matrix [n_jobs, D] float64, errors)`` where ``errors[i]`` is None or the exception of
-    job i (its matrix row is NaN)."""
+    With ``device_prepare`` (default) PCM16 / float32 WAVE payloads go to the GPU as raw bytes and
+    ``_prepare_audio_buffer`` (audio_utils.py:28-60) runs there; other encodings are decoded and
+    prepared on the host as before.  Returns ``(matrix [n_jobs, D] float64, errors)`` where
+    ``errors[i]`` is None or the exception of job i (its matrix row is NaN)."""
     n = len(jobs)
     dim = feature_flags.width()
     matrix = np.full((n, dim), np.nan, dtype=np.float64)
     errors: list[Exception | None] = [None] * n
     if n == 0:
         return matrix, errors
-    packed = [(p, s, d, audio_read_config) for p, s, d in jobs]
+    if feature_flags.tonnetz:
+        raise NotImplementedError("tonnetz features are outside the accelerated path; use FeatureFlags(tonnetz=False)")
+    packed = [(p, s, d, audio_read_config, device_prepare) for p, s, d in jobs]
     if workers > 1 and n > 1:
         with ThreadPoolExecutor(max_workers=workers) as pool:
             decoded = list(pool.map(_read_one, packed))
     else:
         decoded = [_read_one(j) for j in packed]
+    raw_groups: dict[tuple[int, str], list[int]] = {}
     by_rate: dict[int, list[int]] = {}
-    for i, (ok, err) in enumerate(decoded):
-        if err is not None:
+    for i, (kind, value, err) in enumerate(decoded):
+        if kind is None:
             errors[i] = err
+        elif kind == "raw":
+            raw_groups.setdefault((value.sample_rate, value.sample_format), []).append(i)
         else:
-            by_rate.setdefault(int(ok[1]), []).append(i)
+            by_rate.setdefault(int(value[1]), []).append(i)
+    for (rate, sample_format), idxs in raw_groups.items():
+        try:
+            matrix[idxs] = _featurize_raw_group([decoded[i][1] for i in idxs], rate, sample_format, feature_flags)
+        except Exception as err:
+            for i in idxs:
+                errors[i] = err
     backend = HandcraftedBackend(feature_flags=feature_flags)
     for rate, idxs in by_rate.items():
         clips, good = [], []
         for i in idxs:
-            clip = decoded[i][0][0]
+            clip = decoded[i][1][0]
             try:  # per-clip validation errors must not poison the batch
                 from .dsp import validate_signal
 

@@ -129,6 +129,56 @@ class FeatureEngine:
             return out, tuning
         return out
 
+    # ------------------------------------------------------------------ audio preparation
+    def prepare_audio(self, raw, sample_format: str, clip_raw_offset, clip_frames, clip_channels):
+        """Device form of ``_prepare_audio_buffer`` for a batch of raw clips.
+
+        ``raw`` holds the interleaved sample payloads (bytes-like, uint8 numpy array or uint8 torch
+        tensor); ``sample_format`` is ``"s16"`` (little-endian PCM16) or ``"f32"``.  Returns
+        ``(audio, offsets, lengths)``: one float32 device buffer with every clip mono,
+        scrubbed and peak-normalised, and the int64 host descriptors ``features`` takes.
+        """
+        torch = self._torch
+        fmt = {"s16": 0, "f32": 1}.get(sample_format)
+        if fmt is None:
+            raise ValueError("sample_format must be 's16' or 'f32'")
+        if isinstance(raw, torch.Tensor):
+            raw_dev = raw.to(device=self.device).contiguous().view(torch.uint8).reshape(-1)
+        else:
+            raw_dev = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()
+                                       if not isinstance(raw, np.ndarray)
+                                       else np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).to(self.device)
+        off = _as_i64(clip_raw_offset)
+        frames = _as_i64(clip_frames)
+        chans = np.ascontiguousarray(np.asarray(clip_channels, dtype=np.int32))
+        if not (off.shape == frames.shape == chans.shape) or off.ndim != 1:
+            raise ValueError("clip descriptors must be 1-D and the same length")
+        n = int(off.shape[0])
+        out_off = np.zeros(n, dtype=np.int64)
+        if n:
+            np.cumsum(frames[:-1], out=out_off[1:])
+        total = int(frames.sum())
+        with torch.cuda.device(self.device), self._lock:
+            out = torch.empty((total,), dtype=torch.float32, device=self.device)
+            if n:
+                _native.check(
+                    self._lib.serhip_prepare_audio(
+                        self._ctx.handle,
+                        c_void_p(raw_dev.data_ptr()),
+                        int(raw_dev.numel()),
+                        fmt,
+                        off.ctypes.data_as(POINTER(c_int64)),
+                        frames.ctypes.data_as(POINTER(c_int64)),
+                        chans.ctypes.data_as(POINTER(c_int32)),
+                        out_off.ctypes.data_as(POINTER(c_int64)),
+                        n,
+                        c_void_p(out.data_ptr()),
+                        total,
+                        self._stream(),
+                    )
+                )
+        return out, out_off, frames
+
     # ------------------------------------------------------------------ pooling
     def pool_windows(self, embeddings, win_lo, win_hi, *, mode: int):
         """Pool rows ``[lo, hi)`` of ``embeddings`` per window; returns a float64 device tensor."""
