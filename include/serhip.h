@@ -136,6 +136,26 @@ int serhip_prepare_audio(serhip_ctx* ctx, const void* raw_dev, int64_t raw_bytes
                          const int32_t* clip_channels, const int64_t* clip_out_offset, int64_t n_clips,
                          float* out_dev, int64_t out_samples, void* stream);
 
+/* The fast profile's classifier on the device: forward pass of the sklearn
+ * Pipeline(StandardScaler, MLPClassifier) built by ser/_internal/models/training_support.py:87-106,
+ * i.e. model.predict / model.predict_proba as called at ser/_internal/models/fast_path.py:180-192
+ * (SURVEY.md 8f item 3).  All arithmetic in float64, as sklearn does on the reference's matrix.
+ *   x_dev        device, [n_rows, n_features] row-major, float32 (x_is_f64 = 0) or float64 (1)
+ *   mean_dev / scale_dev  device f64 [n_features] (StandardScaler.mean_ / scale_) or NULL
+ *   n_layers     weight matrices (hidden layers + 1); layer_sizes host [n_layers + 1] =
+ *                {n_features, hidden..., n_out}; weights_dev / bias_dev host arrays of n_layers
+ *                device pointers: coefs_[l] as [layer_sizes[l], layer_sizes[l+1]] row-major f64,
+ *                intercepts_[l] as [layer_sizes[l+1]] f64
+ *   hidden_activation  0 identity, 1 relu, 2 tanh, 3 logistic (MLPClassifier.activation)
+ *   out_activation     0 softmax (n_out >= 2 classes), 1 logistic (n_out == 1: two classes)
+ *   proba_dev    device f64 [n_rows, n_classes], n_classes = n_out (softmax) or 2 (logistic)
+ *   label_dev    device int32 [n_rows] index into classes_ (arg-max, first on ties), or NULL */
+int serhip_mlp_predict(serhip_ctx* ctx, const void* x_dev, int x_is_f64, int64_t n_rows, int32_t n_features,
+                       const double* mean_dev, const double* scale_dev, int32_t n_layers,
+                       const int32_t* layer_sizes, const double* const* weights_dev,
+                       const double* const* bias_dev, int hidden_activation, int out_activation,
+                       double* proba_dev, int32_t* label_dev, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on.
  * No reference counterpart (the reference's only timer is the phase stopwatch of
  * ser/_internal/runtime/phase_timing.py:29-78 around whole inferences); bench.py uses

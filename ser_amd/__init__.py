@@ -42,6 +42,12 @@ _LAZY = {
     "LoaderSettings": ("data_loader", "LoaderSettings"),
     "write_prepared_feature_payload": ("prepared_cache", "write_prepared_feature_payload"),
     "read_prepared_feature_payload": ("prepared_cache", "read_prepared_feature_payload"),
+    "GpuEmotionClassifier": ("classifier", "GpuEmotionClassifier"),
+    "predict_emotions_detailed_with_model": ("fast_inference", "predict_emotions_detailed_with_model"),
+    "segment_predictions": ("fast_inference", "segment_predictions"),
+    "InferenceResult": ("fast_inference", "InferenceResult"),
+    "FramePrediction": ("fast_inference", "FramePrediction"),
+    "SegmentPrediction": ("fast_inference", "SegmentPrediction"),
 }
 
 

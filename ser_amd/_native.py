@@ -41,6 +41,11 @@ SIGNATURES: dict[str, tuple] = {
         [c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_int64),
          c_int64, c_void_p, c_int64, c_void_p],
     ),
+    "serhip_mlp_predict": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int64, c_int32, c_void_p, c_void_p, c_int32, POINTER(c_int32),
+         POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p, c_void_p],
+    ),
     "serhip_profile_enable": (c_int, [c_void_p, c_int]),
     "serhip_profile_read": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
     "serhip_host_table": (c_int64, [c_int, c_int, c_int, POINTER(c_float), c_int64]),

@@ -14,6 +14,7 @@
 
 #include "kernels_fast.hpp"
 #include "kernels_generic.hpp"
+#include "kernels_mlp.hpp"
 #include "kernels_prepare.hpp"
 #include "kernels_project.hpp"
 #include "kernels_whisper.hpp"
@@ -791,6 +792,64 @@ int serhip_prepare_audio(serhip_ctx* ctx, const void* raw_dev, int64_t raw_bytes
         hipLaunchKernelGGL(k_prepare_normalise, dim3(gx, gy), dim3(256), 0, stream, d_clips + first, out_dev,
                            d_peak + first);
     }
+    HIP_TRY(hipGetLastError());
+    return SERHIP_OK;
+}
+
+int serhip_mlp_predict(serhip_ctx* ctx, const void* x_dev, int x_is_f64, int64_t n_rows, int32_t n_features,
+                       const double* mean_dev, const double* scale_dev, int32_t n_layers, const int32_t* layer_sizes,
+                       const double* const* weights_dev, const double* const* bias_dev, int hidden_activation,
+                       int out_activation, double* proba_dev, int32_t* label_dev, void* stream_v) {
+    if (!ctx) return fail(SERHIP_E_INVALID, "serhip_mlp_predict: ctx is NULL");
+    if (n_rows < 0) return fail(SERHIP_E_INVALID, "serhip_mlp_predict: n_rows < 0");
+    if (n_rows == 0) return SERHIP_OK;
+    if (!x_dev || !layer_sizes || !weights_dev || !bias_dev || !proba_dev)
+        return fail(SERHIP_E_INVALID, "serhip_mlp_predict: NULL argument");
+    if (n_layers < 1 || n_layers > 16) return fail(SERHIP_E_INVALID, "serhip_mlp_predict: n_layers must be 1..16");
+    if (hidden_activation < 0 || hidden_activation > 3 || (out_activation != 0 && out_activation != 1))
+        return fail(SERHIP_E_INVALID, "serhip_mlp_predict: unknown activation code");
+    if (layer_sizes[0] != n_features) return fail(SERHIP_E_INVALID, "serhip_mlp_predict: layer_sizes[0] != n_features");
+    int max_width = 0;
+    for (int l = 0; l <= n_layers; ++l) {
+        if (layer_sizes[l] < 1) return fail(SERHIP_E_INVALID, "serhip_mlp_predict: empty layer");
+        max_width = std::max(max_width, layer_sizes[l]);
+        if (l < n_layers && (!weights_dev[l] || !bias_dev[l]))
+            return fail(SERHIP_E_INVALID, "serhip_mlp_predict: NULL layer parameters");
+    }
+    const int n_out = layer_sizes[n_layers];
+    if (out_activation == 0 && n_out < 2) return fail(SERHIP_E_INVALID, "serhip_mlp_predict: softmax needs >= 2 outputs");
+    if (out_activation == 1 && n_out != 1)
+        return fail(SERHIP_E_UNSUPPORTED, "serhip_mlp_predict: multi-label logistic outputs are not supported");
+    // rows of a layer's input are staged in LDS: 8 rows x width doubles
+    if (static_cast<size_t>(max_width) * kMlpRows * sizeof(double) > 64 * 1024)
+        return fail(SERHIP_E_UNSUPPORTED, "serhip_mlp_predict: layers wider than 1024 units are not supported");
+    if (n_rows > (static_cast<int64_t>(1) << 31) * kMlpRows / 2)
+        return fail(SERHIP_E_UNSUPPORTED, "serhip_mlp_predict: too many rows per call");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t buf_bytes = align_up(static_cast<size_t>(n_rows) * max_width * sizeof(double), 256);
+    int rc = ensure_workspace(ctx, 2 * buf_bytes);
+    if (rc != SERHIP_OK) return rc;
+    double* ping = reinterpret_cast<double*>(ctx->ws);
+    double* pong = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + buf_bytes);
+    const long long total = static_cast<long long>(n_rows) * n_features;
+    const unsigned gs = static_cast<unsigned>(std::min<long long>((total + 255) / 256, 8192));
+    if (x_is_f64)
+        hipLaunchKernelGGL(k_mlp_scale<double>, dim3(gs), dim3(256), 0, stream, static_cast<const double*>(x_dev),
+                           static_cast<long long>(n_rows), n_features, mean_dev, scale_dev, ping);
+    else
+        hipLaunchKernelGGL(k_mlp_scale<float>, dim3(gs), dim3(256), 0, stream, static_cast<const float*>(x_dev),
+                           static_cast<long long>(n_rows), n_features, mean_dev, scale_dev, ping);
+    const unsigned row_blocks = static_cast<unsigned>((n_rows + kMlpRows - 1) / kMlpRows);
+    for (int l = 0; l < n_layers; ++l) {
+        const int n_in = layer_sizes[l], n_o = layer_sizes[l + 1];
+        const int act = (l + 1 < n_layers) ? hidden_activation : 0;   // the output activation runs in k_mlp_output
+        hipLaunchKernelGGL(k_mlp_dense, dim3(row_blocks), dim3(256), static_cast<size_t>(n_in) * kMlpRows * sizeof(double),
+                           stream, ping, static_cast<long long>(n_rows), n_in, n_o, weights_dev[l], bias_dev[l], act, pong);
+        std::swap(ping, pong);
+    }
+    hipLaunchKernelGGL(k_mlp_output, dim3(static_cast<unsigned>((n_rows + 255) / 256)), dim3(256), 0, stream, ping,
+                       static_cast<long long>(n_rows), n_out, out_activation, proba_dev, label_dev);
     HIP_TRY(hipGetLastError());
     return SERHIP_OK;
 }
