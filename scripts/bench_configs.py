@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE.json parity configurations 1, 2, 4 and 5 on one MI355X
+(config 3 is bench.py's headline line).  Inputs are synthetic and resident in HBM before the
+timed region; each figure is audio-seconds of input per second of wall time, with the
+fraction of the HBM roofline on SURVEY.md 8d's algorithmic bytes.  Writes one JSON document.
+
+    python scripts/bench_configs.py > gpurun_out/configs.json
+"""
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from ser_amd import FeatureFlags, HandcraftedBackend, mean_std_pool, temporal_pooling_windows  # noqa: E402
+from ser_amd.engine import get_engine  # noqa: E402
+from ser_amd.handcrafted import sliding_window_bounds  # noqa: E402
+from ser_amd.synth import harmonic_clips_torch, ravdess_sine_clip, sample_wav_like  # noqa: E402
+
+SR = 16000
+HBM = 8.0e12
+FLAGS = FeatureFlags(tonnetz=False)
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def main():
+    eng = get_engine()
+    res = {}
+    # ---- config 1: one 4.37 s recording, 3 s / 1 s windows (latency case: 5 segments)
+    audio = eng.to_device(sample_wav_like())
+    starts, ends = sliding_window_bounds(int(audio.numel()), SR, 3, 1)
+    offs, lens = starts, ends - starts
+    assert len(offs) == 5
+    dt, out = timed(lambda: eng.features(audio, offs, lens, SR, FLAGS), 50)
+    res["config1"] = {"what": "69 937-sample recording, 5 windows (3 s / 1 s), features on device", "ms": dt * 1e3,
+                      "audio_seconds_per_s": (audio.numel() / SR) / dt}
+    # ---- config 2 scaled: 24 actors x 8 emotions x 60 repetitions of the 1.5 s synthetic RAVDESS clips
+    base = np.stack([ravdess_sine_clip(a, e) for a in range(1, 25) for e in range(1, 9)])
+    base = base / np.abs(base).max(axis=1, keepdims=True)
+    clips = eng.to_device(np.tile(base, (60, 1)).reshape(-1))
+    n = 24 * 8 * 60
+    offs2 = np.arange(n, dtype=np.int64) * 24000
+    lens2 = np.full(n, 24000, dtype=np.int64)
+    dt, out = timed(lambda: eng.features(clips, offs2, lens2, SR, FLAGS), 5)
+    sec = n * 1.5
+    res["config2_scaled"] = {"what": f"{n} clips x 1.5 s (47 frames each)", "ms": dt * 1e3, "audio_seconds_per_s": sec / dt,
+                             "hbm_roofline_frac": (sec / dt) * (4 * 24000 + 4 * 187) / 1.5 / HBM}
+    del clips
+    # ---- config 4: one hour, 3 s windows / 1 s stride through descriptors, then mean_std_pool 10 s / 5 s
+    hour = harmonic_clips_torch(4321, 3600, SR, eng.device).reshape(-1)
+    hour = hour / hour.abs().max()
+    starts, ends = sliding_window_bounds(int(hour.numel()), SR, 3, 1)
+    offs4, lens4 = starts, ends - starts
+    assert len(offs4) == 3600
+    dt, out = timed(lambda: eng.features(hour, offs4, lens4, SR, FLAGS), 10)
+    res["config4"] = {"what": "1 h recording, 3 600 overlapping windows by descriptor (no copies)", "ms": dt * 1e3,
+                      "audio_seconds_per_s": 3600.0 / dt,
+                      "hbm_roofline_frac": (3600.0 / dt) * (4 * SR + 4 * 187) / HBM}
+    backend = HandcraftedBackend(feature_flags=FLAGS)
+    host_hour = hour.cpu().numpy()
+    t0 = time.perf_counter()
+    enc = backend.encode_sequence(host_hour, SR)
+    wins = temporal_pooling_windows(enc, window_size_seconds=10.0, window_stride_seconds=5.0)
+    pooled = mean_std_pool(enc, wins)
+    res["config4_host_api"] = {"what": "same through HandcraftedBackend.encode_sequence (230 MB H2D) + "
+                                       "temporal_pooling_windows + mean_std_pool", "ms": (time.perf_counter() - t0) * 1e3,
+                               "pooled_shape": list(pooled.shape)}
+    del hour
+    # ---- config 5: whisper log-mel, 64 clips x 30 s
+    b = 64
+    clips5 = harmonic_clips_torch(99, b, 30 * SR, eng.device)
+    dt, out = timed(lambda: eng.whisper_logmel(clips5, n_mels=80), 10)
+    sec = b * 30.0
+    res["config5"] = {"what": f"{b} x 30 s clips -> [{b}, 80, 3000] log-mel", "ms": dt * 1e3,
+                      "audio_seconds_per_s": sec / dt, "hbm_roofline_frac": (sec / dt) * 96000 / HBM}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
