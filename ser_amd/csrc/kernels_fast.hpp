@@ -602,15 +602,77 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
     // ---- tuning estimate: median of peak magnitudes, histogram of residuals above it
     if (tid == 0) sh.n_peaks = 0;
     __syncthreads();
+    // per-frame counts: loaded in parallel; for segments of <= 1024 frames they are kept (sh.hist is
+    // free until the select) so that the gather below needs no dependent global loads
+    const bool few_frames = sd.n_stft <= 1024;
     int total = 0;
-    for (int t = tid; t < sd.n_stft; t += blockDim.x) total += sc.peak_cnt[static_cast<size_t>(sd.stft_base) + t];
+    for (int t = tid; t < sd.n_stft; t += blockDim.x) {
+        const int c = sc.peak_cnt[static_cast<size_t>(sd.stft_base) + t];
+        total += c;
+        if (few_frames) sh.hist[t] = static_cast<unsigned>(c);
+    }
     total = wave_sum_int(total);
     if (lane == 0) sh.ired[wave] = total;
     __syncthreads();
     const int n_peaks = sh.ired[0] + sh.ired[1] + sh.ired[2] + sh.ired[3];
     __syncthreads();
     const bool in_lds = n_peaks <= kPeakLdsCap;
-    if (in_lds) {
+    if (in_lds && few_frames) {
+        // exclusive scan of the counts (thread t owns frames 4t..4t+3) -> sh.hist[1024 + frame]
+        unsigned c4[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = 4 * tid + j;
+            c4[j] = idx < sd.n_stft ? sh.hist[idx] : 0u;
+            mine += c4[j];
+        }
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) sh.ired[wave] = static_cast<int>(incl);
+        __syncthreads();
+        unsigned excl = incl - mine;
+        for (int w = 0; w < wave; ++w) excl += static_cast<unsigned>(sh.ired[w]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = 4 * tid + j;
+            if (idx < sd.n_stft) sh.hist[1024 + idx] = excl;
+            excl += c4[j];
+        }
+        __syncthreads();
+        // gather: 16 lanes per frame, 4 frames in flight per lane group, all loads independent
+        const int g = tid >> 4, l16 = tid & 15;
+        for (int t0 = g; t0 < sd.n_stft; t0 += 64) {
+            v2f val[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 16 * u;
+                dst[u] = -1;
+                if (t < sd.n_stft && l16 < static_cast<int>(sh.hist[t])) {
+                    val[u] = sc.peaks[(static_cast<size_t>(sd.stft_base) + t) * sc.peak_cap + l16];
+                    dst[u] = static_cast<int>(sh.hist[1024 + t]) + l16;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) sh.peaks[dst[u]] = val[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // frames with more than 16 peaks
+                const int t = t0 + 16 * u;
+                if (t < sd.n_stft) {
+                    const int c = static_cast<int>(sh.hist[t]), o = static_cast<int>(sh.hist[1024 + t]);
+                    for (int j = l16 + 16; j < c; j += 16)
+                        sh.peaks[o + j] = sc.peaks[(static_cast<size_t>(sd.stft_base) + t) * sc.peak_cap + j];
+                }
+            }
+        }
+        if (tid == 0) sh.n_peaks = n_peaks;
+        __syncthreads();
+    } else if (in_lds) {
         for (int t = wave; t < sd.n_stft; t += 4) {
             const size_t row = static_cast<size_t>(sd.stft_base) + t;
             const int c = sc.peak_cnt[row];
