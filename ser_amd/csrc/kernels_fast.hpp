@@ -99,10 +99,17 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// max over the 64 lanes, returned to every lane.  DPP only (quad swaps, half-row and row mirrors, then
+// the gfx9 row broadcasts): six v_max_f32 and a readlane instead of six ds_bpermute round trips.
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));   // row_mirror: every row of 16 now holds its max
+    // row_bcast:15 (rows 1 and 3 take lane 15 of the row before), row_bcast:31 (rows 2-3 take lane 31)
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xC, 0xF, false)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -300,7 +307,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             // comparing the raw neighbours (a neighbour <= ref is < s0 either way)
             auto scan_stripe = [&](int r, float s0) {
                 const int k = lane + 64 * r;
-                const bool cand_ok = (s0 > ref) && (k >= tb.kmin) && (k <= tb.kmax);
+                bool cand_ok = s0 > ref;
+                if (64 * r < tb.kmin || 64 * r + 63 > tb.kmax)   // scalar: only the edge stripes check the range
+                    cand_ok = cand_ok && (k >= tb.kmin) && (k <= tb.kmax);
                 if (__ballot(cand_ok) == 0ull) return;   // wave-uniform: most stripes hold nothing above ref
                 bool is_peak = false;
                 if (cand_ok) is_peak = (s0 > sM[k - 1]) && (s0 >= sM[k + 1]);
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             };
 #pragma unroll
             for (int r = 0; r < 8; ++r)
-                if (64 * r <= tb.kmax) scan_stripe(r, mlo[r]);
+                if (64 * r <= tb.kmax && 64 * r + 63 >= tb.kmin) scan_stripe(r, mlo[r]);
             for (int r = 8; 64 * r <= tb.kmax; ++r) scan_stripe(r, sM[lane + 64 * r]);   // sample rates < 16 kHz
             wave_lds_sync();
             v2f* prow = sc.peaks + row * sc.peak_cap;
