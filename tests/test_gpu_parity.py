@@ -136,6 +136,38 @@ def test_other_sample_rates(engine, flags):
         assert_features_close(got, want)
 
 
+def test_low_and_high_sample_rates(engine, flags):
+    """11 025 / 12 000 Hz: the piptrack range (150-4000 Hz) extends past bin 511, the stripes the FFT
+    kernel scans from LDS instead of registers; contrast is off (the reference raises for sr <= 12 800).
+    8 000 Hz: the range ends one bin below the Nyquist row.
+    96 000 Hz: the low mel filters are narrower than an FFT bin and several 16-filter blocks share groups."""
+    from ser_amd import FeatureFlags
+    from ser_amd.synth import harmonic_clip
+    from oracle import ser_fast_path as ofp
+
+    for sr in (11025, 12000):
+        fl = FeatureFlags(mfcc=True, chroma=True, mel=True, contrast=False, tonnetz=False)
+        a = harmonic_clip(np.random.default_rng(sr), 2 * sr, sr)
+        got, tun = gpu_rows(engine, fl, a, [0, 100], [a.size, 5000], sr=sr)
+        want, wtun = oracle_rows(a, [0, 100], [a.size, 5000], sr=sr, oflags=ofp.Flags(contrast=False))
+        np.testing.assert_allclose(tun, wtun, atol=1e-6)
+        pad = np.zeros((2, 7))   # these plans have no contrast block: append the zeros the checker expects
+        assert_features_close(np.hstack([got, pad]), np.hstack([want, pad]))
+    # 8 000 Hz: the piptrack range ends at bin 1023, one below the Nyquist row
+    fl = FeatureFlags(mfcc=True, chroma=True, mel=True, contrast=False, tonnetz=False)
+    a = harmonic_clip(np.random.default_rng(8), 16000, 8000)
+    got, tun = gpu_rows(engine, fl, a, [0], [a.size], sr=8000)
+    want, wtun = oracle_rows(a, [0], [a.size], sr=8000, oflags=ofp.Flags(contrast=False))
+    np.testing.assert_allclose(tun, wtun, atol=1e-6)
+    pad = np.zeros((1, 7))
+    assert_features_close(np.hstack([got, pad]), np.hstack([want, pad]))
+    a = harmonic_clip(np.random.default_rng(96), 96000, 96000)
+    got, tun = gpu_rows(engine, flags, a, [0], [a.size], sr=96000)
+    want, wtun = oracle_rows(a, [0], [a.size], sr=96000)
+    np.testing.assert_allclose(tun, wtun, atol=1e-6)
+    assert_features_close(got, want)
+
+
 def test_flag_subsets(engine, flags):
     """Every block is computed identically whatever the other flags are; order mfcc|chroma|mel|contrast."""
     from ser_amd import FeatureFlags
