@@ -41,7 +41,20 @@ __device__ __forceinline__ v2f sub_neg_i(v2f a, v2f b) {   // a - (-i) b = (a.x 
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// the two sums of the real-FFT unpack, one instruction each
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {    // a + conj(b) = (a.x + b.x, a.y - b.y)
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f sub_conj_neg_i(v2f a, v2f b) {   // -i (a - conj(b)) = (a.y + b.y, b.x - a.x)
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 #else
+SERHIP_HD v2f add_conj(v2f a, v2f b) { return v2f{a.x + b.x, a.y - b.y}; }
+SERHIP_HD v2f sub_conj_neg_i(v2f a, v2f b) { return v2f{a.y + b.y, b.x - a.x}; }
 SERHIP_HD v2f cmul(v2f a, v2f b) {
     return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             const int kk = (1024 - k) & 1023;
             const v2f za = buf[k + 4 * (r >> 2)];
             const v2f zb = buf[kk + 4 * (kk >> 8)];
-            const v2f e2 = v2f{za.x + zb.x, za.y - zb.y};       // 2E
-            const v2f o2 = v2f{za.y + zb.y, zb.x - za.x};       // 2O
+            const v2f e2 = add_conj(za, zb);           // E  (the window is pre-halved)
+            const v2f o2 = sub_conj_neg_i(za, zb);     // O
             const v2f t2 = cmul(o2, s_twU[r * 64 + lane]);
             const v2f xlo = e2 + t2;
             const v2f xhi = e2 - t2;
