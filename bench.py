@@ -82,6 +82,9 @@ def main() -> None:
     ap.add_argument("--clips-per-gpu", type=int, default=CLIPS_PER_GPU)
     ap.add_argument("--cpu-clips", type=int, default=800, help="clips in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=8)
+    # rehearsal of the N > 1 code path on a one-GPU box: every rank on the same device, gloo for the
+    # collectives (features are copied to the host for the gather).  Not a measurement.
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,11 +108,16 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     n_local = int(args.clips_per_gpu)
     n_total = n_local * world
@@ -123,6 +131,8 @@ def main() -> None:
 
     def step():
         feats = engine.features(audio, offsets, lengths, SAMPLE_RATE, flags)
+        if args.rehearse_on_one_gpu and world > 1:
+            return all_gather_rows(feats.cpu(), n_total).to(device)
         return all_gather_rows(feats, n_total)
 
     def fence():
@@ -147,7 +157,7 @@ def main() -> None:
     assert tuple(out.shape) == (n_total, FEATURE_DIM)
     assert bool(torch.isfinite(out).all())
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -162,7 +172,10 @@ def main() -> None:
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("k_stft_frames_hbm_bytes_per_launch")
+                prof = json.loads(tfile.read_text())
+                # PMC bytes of one profiled launch, scaled to this run's clips per launch
+                traffic = prof["k_stft_frames_hbm_bytes_per_launch"] * (
+                    n_local / max(1, k1_n / max(1, args.steps)) / prof["k_stft_frames_segments_per_launch_avg"])
             except Exception:
                 traffic = None
         line = {
@@ -177,7 +190,7 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {
                 "workload": "config 3: 100k x 3 s clips @16 kHz sharded by utterance, 12 500 clips per GPU, "
                             "187-dim fast-profile features (mfcc40|chroma12|mel128|contrast7) + all-gather",
