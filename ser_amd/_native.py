@@ -77,6 +77,14 @@ def load_library() -> ctypes.CDLL:
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  ser_amd has no CPU fallback."
             )
+        # torch ships its own HIP runtime (libamdhip64.so.7 under torch/lib) and loads it by absolute
+        # path.  libserhip.so must bind to THAT copy -- it is handed torch's device pointers and
+        # streams -- so torch has to be in the process first; loaded the other way round, the system
+        # runtime and torch's both initialise and the second one finds no device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # pragma: no cover - a torch-less caller owns its HIP runtime
+            pass
         lib = ctypes.CDLL(str(path))
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here means the .so is stale

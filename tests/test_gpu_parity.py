@@ -55,6 +55,21 @@ def test_loaded_native_library(engine):
     assert _native.load_library().serhip_version() >= 100
 
 
+def test_driver_entry_points_in_a_fresh_process():
+    """``build()`` then ``smoke()`` exactly as the driver calls them: a new interpreter in which the
+    shared library is touched before anything has imported torch (two HIP runtimes in one process
+    was a real failure: the second to initialise sees no device)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = "import __graft_entry__ as g; g.build(); g.smoke()"
+    res = subprocess.run([sys.executable, "-c", code], cwd=str(root), capture_output=True, text=True, timeout=170)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "smoke ok" in res.stdout
+
+
 def test_config3_clips_batch(engine, flags):
     """Config 3 shape (3 s clips @16 kHz, harmonics + noise), 24 clips."""
     from ser_amd.synth import harmonic_clips
