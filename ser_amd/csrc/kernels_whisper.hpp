@@ -19,7 +19,8 @@ constexpr int kWNfft = 400;
 constexpr int kWHop = 160;
 constexpr int kWBins = 201;
 constexpr int kWHalf = 200;          // packed complex points per frame
-constexpr int kWTile = 64;           // frames per workgroup
+constexpr int kWWaves = 12;          // waves per workgroup (3 per SIMD; ~150 KB of LDS, one workgroup per CU)
+constexpr int kWTile = 96;           // frames per workgroup
 constexpr int kWMelWCap = 1024;      // sparse mel taps (80 mels: ~400, 128 mels: ~500)
 
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -40,28 +41,28 @@ struct WhisperTables {
 // pass 1: log10(max(mel, 1e-10)) into out[clip][m][t] and the running clip maximum.
 // The 400-point DFT is accumulated in double: bins 80 dB below the clip maximum still have to
 // agree with a float64 STFT to ~1e-4 relative, which a float32 transform does not deliver.
-__global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict__ audio, long long n_samples,
+__global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __restrict__ audio, long long n_samples,
                                                         int n_frames, WhisperTables wt, float* __restrict__ out,
                                                         unsigned* __restrict__ clip_max) {
     __shared__ v2d s_tw200[kWHalf];
     __shared__ v2d s_tw400[kWBins + 1];
     __shared__ double s_win[kWNfft];
     __shared__ float s_melw[kWMelWCap];
-    __shared__ v2d s_z[4][kWHalf];
-    __shared__ v2d s_y[4][kWHalf];
-    __shared__ float s_p[4][kWBins + 3];
+    __shared__ v2d s_z[kWWaves][kWHalf];
+    __shared__ v2d s_y[kWWaves][kWHalf];
+    __shared__ float s_p[kWWaves][kWBins + 3];
     __shared__ float s_tile[128][kWTile + 1];
-    __shared__ float s_red[4];
+    __shared__ float s_red[kWWaves];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int clip = blockIdx.y;
     const int t_tile = blockIdx.x * kWTile;
     const float* x = audio + static_cast<size_t>(clip) * n_samples;
 
-    for (int i = tid; i < kWHalf; i += 256) s_tw200[i] = wt.tw200[i];
-    for (int i = tid; i < kWBins; i += 256) s_tw400[i] = wt.tw400[i];
-    for (int i = tid; i < kWNfft; i += 256) s_win[i] = wt.win[i];
-    for (int i = tid; i < wt.mel_nnz; i += 256) s_melw[i] = wt.mel_w[i];
+    for (int i = tid; i < kWHalf; i += kWWaves * 64) s_tw200[i] = wt.tw200[i];
+    for (int i = tid; i < kWBins; i += kWWaves * 64) s_tw400[i] = wt.tw400[i];
+    for (int i = tid; i < kWNfft; i += kWWaves * 64) s_win[i] = wt.win[i];
+    for (int i = tid; i < wt.mel_nnz; i += kWWaves * 64) s_melw[i] = wt.mel_w[i];
     __syncthreads();
 
     const int4 rng0 = (lane < wt.n_mels) ? wt.mel_rng[lane] : int4{0, 0, 0, 0};
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict_
     float* p = s_p[wave];
     float vmax = -INFINITY;
 
-    for (int f = wave; f < kWTile; f += 4) {
+    for (int f = wave; f < kWTile; f += kWWaves) {
         const int t = t_tile + f;
         if (t >= n_frames) break;
         // ---- framing with reflect padding (200 samples each side) + Hann
@@ -89,42 +90,61 @@ __global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict_
             }
         }
         wave_lds_sync();
-        // ---- step 1: Y[k1][n2] = sum_{n1<25} z[8 n1 + n2] W_25^(n1 k1), then * W_200^(n2 k1)
+        // ---- step 1: Y[k1][n2] = sum_{n1<25} z[8 n1 + n2] W_25^(n1 k1), then * W_200^(n2 k1).
+        // Output o = lane + 64 i has n2 = lane & 7 for every i, so the four outputs of a lane share each
+        // z read; their twiddles W_25^(n1 k1) advance by a complex multiplication (double precision:
+        // 24 steps cost ~1e-15) instead of a table read.  LDS reads per lane: 25 + 8 instead of 200.
+        {
+            const int n2 = lane & 7;
+            v2d acc[4], w[4], step[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = lane + 64 * i;
-            if (o < kWHalf) {
-                const int k1 = o >> 3, n2 = o & 7;
-                v2d acc = v2d{0.0, 0.0};
-                int e = 0;  // (8 * n1 * k1) mod 200
-                for (int n1 = 0; n1 < 25; ++n1) {
-                    acc += cmuld(z[8 * n1 + n2], s_tw200[e]);
-                    e += 8 * k1;
-                    if (e >= kWHalf) e -= kWHalf;
+            for (int i = 0; i < 4; ++i) {
+                const int k1 = min((lane >> 3) + 8 * i, 24);
+                acc[i] = v2d{0.0, 0.0};
+                w[i] = v2d{1.0, 0.0};
+                step[i] = s_tw200[(8 * k1) % kWHalf];   // W_25^k1
+            }
+            for (int n1 = 0; n1 < 25; ++n1) {
+                const v2d zz = z[8 * n1 + n2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i] += cmuld(zz, w[i]);
+                    w[i] = cmuld(w[i], step[i]);
                 }
-                y[o] = cmuld(acc, s_tw200[n2 * k1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = lane + 64 * i;
+                if (o < kWHalf) y[o] = cmuld(acc[i], s_tw200[n2 * (o >> 3)]);
             }
         }
         wave_lds_sync();
-        // ---- step 2: Z[k1 + 25 k2] = sum_{n2<8} Y'[k1][n2] W_8^(n2 k2)
+        // ---- step 2: Z[k1 + 25 k2] = sum_{n2<8} Y'[k1][n2] W_8^(n2 k2).  Lane (k1, half) reads the 8
+        // values of its k1 once and produces k2 = 4 half + j, j = 0..3: W_8^(n2 k2) = W_8^(n2 j) (-1)^(n2 half),
+        // compile-time eighth roots of unity after the odd terms are negated for half = 1.
         v2d zk[4];
+        const int k1s = lane % 25, half = lane / 25;
+        if (lane < 50) {
+            const double r = 0.70710678118654752440;
+            const v2d w8[8] = {v2d{1.0, 0.0}, v2d{r, -r}, v2d{0.0, -1.0}, v2d{-r, -r},
+                               v2d{-1.0, 0.0}, v2d{-r, r}, v2d{0.0, 1.0}, v2d{r, r}};
+            v2d yy[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = lane + 64 * i;
-            zk[i] = v2d{0.0, 0.0};
-            if (o < kWHalf) {
-                const int k1 = o % 25, k2 = o / 25;
-                v2d acc = v2d{0.0, 0.0};
+            for (int n2 = 0; n2 < 8; ++n2) {
+                yy[n2] = y[k1s * 8 + n2];
+                if ((n2 & 1) && half) yy[n2] = -yy[n2];
+            }
 #pragma unroll
-                for (int n2 = 0; n2 < 8; ++n2) acc += cmuld(y[k1 * 8 + n2], s_tw200[(25 * n2 * k2) % kWHalf]);
-                zk[i] = acc;
+            for (int j = 0; j < 4; ++j) {
+                v2d acc = yy[0];
+#pragma unroll
+                for (int n2 = 1; n2 < 8; ++n2) acc += cmuld(yy[n2], w8[(n2 * j) & 7]);
+                zk[j] = acc;
             }
         }
-        wave_lds_sync();
+        if (lane < 50) {   // z was last read in step 1, two barriers ago
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = lane + 64 * i;
-            if (o < kWHalf) z[o] = zk[i];
+            for (int j = 0; j < 4; ++j) z[k1s + 25 * (4 * half + j)] = zk[j];
         }
         wave_lds_sync();
         // ---- real-FFT unpack to bins 0..200 and |X|^2
@@ -166,14 +186,15 @@ __global__ __launch_bounds__(256) void k_whisper_frames(const float* __restrict_
     if (lane == 0) s_red[wave] = vmax;
     __syncthreads();
     if (tid == 0) {
-        const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        float m = s_red[0];
+        for (int w = 1; w < kWWaves; ++w) m = fmaxf(m, s_red[w]);
         if (m > -INFINITY) atomicMax(&clip_max[clip], float_key(m));
     }
     // ---- coalesced store of the [n_mels][tile] block (frames are the minor axis)
     const int valid = min(kWTile, n_frames - t_tile);
     float* o = out + static_cast<size_t>(clip) * wt.n_mels * n_frames + t_tile;
-    for (int i = tid; i < wt.n_mels * kWTile; i += 256) {
-        const int m = i >> 6, f = i & 63;
+    for (int i = tid; i < wt.n_mels * kWTile; i += kWWaves * 64) {
+        const int m = i / kWTile, f = i - m * kWTile;
         if (f < valid) o[static_cast<size_t>(m) * n_frames + f] = s_tile[m][f];
     }
 }

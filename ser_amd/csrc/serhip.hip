@@ -352,7 +352,7 @@ int whisper_logmel_launch(serhip_ctx* ctx, const float* audio_dev, int32_t n_cli
     const int n_frames = static_cast<int>(n_samples / kWHop);
     const WhisperTables& wt = ctx->whisper_tb[n_mels == 80 ? 0 : 1];
     const dim3 grid((n_frames + kWTile - 1) / kWTile, static_cast<unsigned>(n_clips));
-    hipLaunchKernelGGL(k_whisper_frames, grid, dim3(256), 0, stream, audio_dev, static_cast<long long>(n_samples),
+    hipLaunchKernelGGL(k_whisper_frames, grid, dim3(kWWaves * 64), 0, stream, audio_dev, static_cast<long long>(n_samples),
                        n_frames, wt, out_dev, clip_max);
     const long long per_clip = static_cast<long long>(n_mels) * n_frames;
     const unsigned gx = static_cast<unsigned>(std::min<long long>((per_clip + 255) / 256, 4096));
