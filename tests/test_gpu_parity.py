@@ -130,6 +130,23 @@ def test_ragged_unaligned_and_short_segments(engine, flags):
     assert_features_close(got, want)
 
 
+def test_long_single_segments(engine, flags):
+    """Segments of more than 1024 frames take the tuning kernel's other gather paths: (a) many peaks
+    (streamed from the scratch, never staged in LDS), (b) few peaks in a long, mostly silent
+    recording (staged in LDS by the sequential gather)."""
+    from ser_amd.synth import harmonic_clip
+
+    n = 40 * SR                                      # 1251 frames
+    a = harmonic_clip(np.random.default_rng(40), n, SR)
+    b = np.zeros(n, dtype=np.float32)
+    b[5 * SR : 6 * SR] = harmonic_clip(np.random.default_rng(41), SR, SR)
+    audio = np.concatenate([a, b])
+    got, tun = gpu_rows(engine, flags, audio, [0, n], [n, n])
+    want, wtun = oracle_rows(audio, [0, n], [n, n])
+    np.testing.assert_allclose(tun, wtun, atol=1e-6)
+    assert_features_close(got, want)
+
+
 def test_silence_and_constant(engine, flags):
     z = np.zeros(9000, np.float32)
     got, tun = gpu_rows(engine, flags, z, [0, 100], [9000, 1000])
