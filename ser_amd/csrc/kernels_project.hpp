@@ -25,6 +25,7 @@ namespace serhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kProjTile = 32;   // frames per wave
+constexpr int kProjWaves = 3;   // waves per workgroup: one B row each to fetch; 96 frames = one 3 s clip
 
 __device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
@@ -41,16 +42,16 @@ __device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 c) {
 // (PlanTables::mel_prog): which B rows the two slots use (row 0 is all zeros), which slots are live,
 // and how many blocks retire after the group.  All operands of group G + 1 are requested before the
 // MFMAs of group G are issued.
-__global__ __launch_bounds__(256) void k_project_frames(const SegDesc* __restrict__ segs, PlanTables tb, Scratch sc) {
-    // B rows of the current and the next group, shared by the four waves (all work on one segment, so on
+__global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDesc* __restrict__ segs, PlanTables tb, Scratch sc) {
+    // B rows of the current and the next group, shared by the three waves (all work on one segment, so on
     // one tuning): [stage][0 chroma | 1 mel slot lo | 2 mel slot hi][lane]
     __shared__ float4 s_b[2][3][64];
     __shared__ int4 s_prog[kGroups];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const SegDesc sd = segs[blockIdx.y];
-    if (blockIdx.x * 4 * kProjTile >= sd.n_stft) return;   // whole workgroup
-    const int t0 = (blockIdx.x * 4 + wave) * kProjTile;
+    if (blockIdx.x * kProjWaves * kProjTile >= sd.n_stft) return;   // whole workgroup
+    const int t0 = (blockIdx.x * kProjWaves + wave) * kProjTile;
     const bool active = t0 < sd.n_stft;   // a wave without a tile still fetches B rows and joins the barriers
     const bool want_chroma = (tb.flags & 2u) != 0, want_mel = (tb.flags & 5u) != 0;
     const int i = lane & 15, kk = lane >> 4;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void k_project_frames(const SegDesc* __restric
     // not stored.  A second tile that lies wholly past the end is replaced by the first; a wave without a
     // tile reads the workgroup's first tile and discards it.  Every wave issues the same three loads per
     // group, unconditionally: the waits in the loop are then exact vmcnt(n) counts and the prefetch holds.
-    const size_t f0 = static_cast<size_t>(sd.stft_base) + (active ? t0 : blockIdx.x * 4 * kProjTile);
+    const size_t f0 = static_cast<size_t>(sd.stft_base) + (active ? t0 : blockIdx.x * kProjWaves * kProjTile);
     const float4* a0p = reinterpret_cast<const float4*>(sc.mags) + (f0 >> 4) * kGroups * 64 + i * 4 + kk;
     const float4* a1p = (active && t0 + 16 < sd.n_stft) ? a0p + kGroups * 64 : a0p;
     const float4* cb = tb.chroma_b + (want_chroma ? static_cast<size_t>(sc.tuning_idx[blockIdx.y]) * kGroups * 64 : 0) + lane;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_project_frames(const SegDesc* __restric
         ++cur;
     };
     // wave w fetches B row w of a group (0 chroma, 1 mel slot lo, 2 mel slot hi).  A wave with nothing to
-    // fetch (wave 3, an idle mel slot, chroma off) still loads a row some other wave of this group needs
+    // fetch (an idle mel slot, chroma off) still loads a row some other wave of this group needs
     // -- never the shared all-zero row 0, which every workgroup on the chip would hammer in L2.
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     auto fetch_b = [&](int G, const int4& p) {
@@ -155,12 +156,12 @@ __global__ __launch_bounds__(256) void k_project_frames(const SegDesc* __restric
     // Software pipeline over two register sets (E for even groups, O for odd), no register copies:
     // step G requests the B row of G + 2 first, multiplies group G, stores the B row of G + 1 (requested
     // a step ago) to LDS and then requests the A rows of G + 2.
-    for (int j = threadIdx.x; j < kGroups; j += 256) s_prog[j] = tb.mel_prog[j];
+    for (int j = threadIdx.x; j < kGroups; j += kProjWaves * 64) s_prog[j] = tb.mel_prog[j];
     float4 aE0 = a0p[0], aE1 = a1p[0], aO0 = a0p[64], aO1 = a1p[64];
     __syncthreads();
     float4 bE = fetch_b(0, prog_at(0));
     float4 bO = fetch_b(1, prog_at(1));
-    if (wave < 3) s_b[0][wave][lane] = bE;
+    s_b[0][wave][lane] = bE;
     __syncthreads();
 
 #pragma unroll 1
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_project_frames(const SegDesc* __restric
         // even group G: stage 0 holds its B rows
         bE = fetch_b(G + 2, prog_at(G + 2));            // G + 2 <= 64
         compute(G, aE0, aE1, prog_at(G));
-        if (wave < 3) s_b[1][wave][lane] = bO;          // B rows of G + 1
+        s_b[1][wave][lane] = bO;                        // B rows of G + 1
         aE0 = a0p[(G + 2) * 64];
         aE1 = a1p[(G + 2) * 64];
         __syncthreads();
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void k_project_frames(const SegDesc* __restric
         const int G3 = min(G + 3, kGroups - 1);         // the last odd step re-reads group 64 (unused)
         bO = fetch_b(G3, prog_at(G3));
         compute(G + 1, aO0, aO1, prog_at(G + 1));
-        if (wave < 3) s_b[0][wave][lane] = bE;          // B rows of G + 2
+        s_b[0][wave][lane] = bE;                        // B rows of G + 2
         aO0 = a0p[G3 * 64];
         aO1 = a1p[G3 * 64];
         __syncthreads();

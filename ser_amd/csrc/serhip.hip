@@ -669,7 +669,8 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
             if (want_proj) {
                 const int tiles = (c.max_frames + kProjTile - 1) / kProjTile;
                 LaunchTimer lt(ctx, SERHIP_KERNEL_PROJECT_FRAMES, stream);
-                hipLaunchKernelGGL(k_project_frames, dim3((tiles + 3) / 4, static_cast<unsigned>(c.count)), dim3(256), 0,
+                hipLaunchKernelGGL(k_project_frames, dim3((tiles + kProjWaves - 1) / kProjWaves, static_cast<unsigned>(c.count)),
+                                   dim3(kProjWaves * 64), 0,
                                    stream, dd, plan->tb, sf);
             }
             {
