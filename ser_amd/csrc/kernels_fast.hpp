@@ -392,7 +392,7 @@ struct FinishShared {
     int ired[8];
     double lmean[kMels];
     double melsum[2][kMels];
-    double lsum[2][kMels];
+    double lsum[kMode == 2 ? 8 : 2][kMels];
     float chroma_acc[4][16];
     unsigned sel_prefix, sel_k;
     int n_peaks;
@@ -560,23 +560,61 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         __syncthreads();
         lmax = fmaxf(fmaxf(sh.red[0], sh.red[1]), fmaxf(sh.red[2], sh.red[3]));
         const float floor_db = lmax - 80.0f;
-        double ls = 0.0;
-        if (want_mfcc) {
-            for (int t = half; t < sd.n_mel; t += 2) {
-                const float v = mel[static_cast<size_t>(t) * kMels + m];
-                const float db = (kMode == 2) ? v : 10.0f * log10f(fmaxf(1e-10f, v));
-                ls += static_cast<double>(fmaxf(db, floor_db));
+        if constexpr (kMode == 2) {
+            // dB rows as float4: thread (4 filters, 1 of 8 frame phases) -> 12 wide loads per 94-frame clip
+            // instead of 47 narrow ones; the 8 partial sums per filter are combined in a fixed order
+            const int m4 = tid & 31, part = tid >> 5;
+            double l4[4] = {0.0, 0.0, 0.0, 0.0};
+            if (want_mfcc) {
+                const float4* mel4 = reinterpret_cast<const float4*>(mel);
+                for (int t = part; t < sd.n_mel; t += 8) {
+                    const float4 v = mel4[static_cast<size_t>(t) * 32 + m4];
+                    l4[0] += static_cast<double>(fmaxf(v.x, floor_db));
+                    l4[1] += static_cast<double>(fmaxf(v.y, floor_db));
+                    l4[2] += static_cast<double>(fmaxf(v.z, floor_db));
+                    l4[3] += static_cast<double>(fmaxf(v.w, floor_db));
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh.lsum[part][4 * m4 + j] = l4[j];
+        } else {
+            double ls = 0.0;
+            if (want_mfcc) {
+                for (int t = half; t < sd.n_mel; t += 2) {
+                    const float v = mel[static_cast<size_t>(t) * kMels + m];
+                    ls += static_cast<double>(fmaxf(10.0f * log10f(fmaxf(1e-10f, v)), floor_db));
+                }
+            }
+            sh.lsum[half][m] = ls;
         }
-        sh.lsum[half][m] = ls;
         __syncthreads();
         const double inv_t = 1.0 / static_cast<double>(sd.n_mel);
         if (tid < kMels) {
-            sh.lmean[tid] = (sh.lsum[0][tid] + sh.lsum[1][tid]) * inv_t;
+            double lsum = sh.lsum[0][tid] + sh.lsum[1][tid];
+            if constexpr (kMode == 2) {
+#pragma unroll
+                for (int q = 2; q < 8; ++q) lsum += sh.lsum[q][tid];
+            }
+            sh.lmean[tid] = lsum * inv_t;
             if (want_mel) orow[off_mel + tid] = static_cast<float>((sh.melsum[0][tid] + sh.melsum[1][tid]) * inv_t);
         }
         __syncthreads();
-        if (want_mfcc && tid < kMfcc) {
+        if constexpr (kMode == 2) {
+            // 40 x 128 DCT on all four waves: thread (coefficient, quarter of the mel axis)
+            const int k = tid & 63, quarter = tid >> 6;
+            double acc = 0.0;
+            if (want_mfcc && k < kMfcc) {
+                const float* d = tb.dct + k * kMels + 32 * quarter;
+#pragma unroll 8
+                for (int j = 0; j < 32; ++j) acc = fma(static_cast<double>(d[j]), sh.lmean[32 * quarter + j], acc);
+            }
+            double* partial = &sh.melsum[0][0];   // 256 doubles; melsum itself was consumed above
+            partial[tid] = acc;
+            __syncthreads();
+            if (want_mfcc && tid < kMfcc)
+                orow[off_mfcc + tid] = static_cast<float>((partial[tid] + partial[64 + tid]) +
+                                                          (partial[128 + tid] + partial[192 + tid]));
+        } else if (want_mfcc && tid < kMfcc) {
             double acc = 0.0;
             const float* d = tb.dct + tid * kMels;
             for (int j = 0; j < kMels; ++j) acc = fma(static_cast<double>(d[j]), sh.lmean[j], acc);
