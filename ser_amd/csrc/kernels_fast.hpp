@@ -213,6 +213,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         }
     };
     const v2f rot3 = (q == 3) ? v2f{0.0f, -1.0f} : v2f{1.0f, 0.0f};   // lane 3 of a quad turns by -i
+    // bit r: bin lane + 64 r lies in the piptrack range [kmin, kmax] (one VGPR instead of a set of
+    // hoisted scalar conditions per stripe, which spilled SGPRs)
+    unsigned in_range = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (lane + 64 * r >= tb.kmin && lane + 64 * r <= tb.kmax) in_range |= 1u << r;
     // one frame, consumed from v (the raw sample pairs loaded by load_frame)
     auto transform_frame = [&](v2f (&v)[16]) {
         // s_win holds HALF the Hann window: the FFT is linear and halving is exact, so the unpack below
@@ -307,19 +313,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             // comparing the raw neighbours (a neighbour <= ref is < s0 either way)
             auto scan_stripe = [&](int r, float s0) {
                 const int k = lane + 64 * r;
-                bool cand_ok = s0 > ref;
-                if (64 * r < tb.kmin || 64 * r + 63 > tb.kmax)   // scalar: only the edge stripes check the range
-                    cand_ok = cand_ok && (k >= tb.kmin) && (k <= tb.kmax);
+                const bool cand_ok = (s0 > ref) & (((in_range >> r) & 1u) != 0u);
                 if (__ballot(cand_ok) == 0ull) return;   // wave-uniform: most stripes hold nothing above ref
-                bool is_peak = false;
-                if (cand_ok) is_peak = (s0 > sM[k - 1]) && (s0 >= sM[k + 1]);
+                // both neighbours are read unconditionally and the tests combined without short-circuit
+                // branches: one LDS round trip per stripe instead of two nested ones
+                const float sm = sM[max(k - 1, 0)], sp = sM[k + 1];
+                const bool is_peak = cand_ok & (s0 > sm) & (s0 >= sp);
                 const unsigned long long mask = __ballot(is_peak);
                 if (is_peak) cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = k;
                 base += __popcll(mask);
             };
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (64 * r <= tb.kmax && 64 * r + 63 >= tb.kmin) scan_stripe(r, mlo[r]);
+            for (int r = 0; r < 8; ++r) scan_stripe(r, mlo[r]);
             for (int r = 8; 64 * r <= tb.kmax; ++r) scan_stripe(r, sM[lane + 64 * r]);   // sample rates < 16 kHz
             wave_lds_sync();
             v2f* prow = sc.peaks + row * sc.peak_cap;
