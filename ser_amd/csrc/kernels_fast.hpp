@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fft_math.hpp"
 #include "tables.hpp"
 
@@ -120,6 +122,20 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+}
+
+// the same reduction on unsigned integers (bit patterns of non-negative floats)
+__device__ __forceinline__ unsigned wave_max_bits(unsigned v) {
+    auto dpp = [](unsigned x, auto ctrl) {
+        return static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v = max(v, dpp(v, std::integral_constant<int, 0xB1>{}));
+    v = max(v, dpp(v, std::integral_constant<int, 0x4E>{}));
+    v = max(v, dpp(v, std::integral_constant<int, 0x141>{}));
+    v = max(v, dpp(v, std::integral_constant<int, 0x140>{}));
+    v = max(v, static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x142, 0xA, 0xF, false)));
+    v = max(v, static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x143, 0xC, 0xF, false)));
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 
 // piptrack arithmetic for one local maximum (librosa.piptrack, called from estimate_tuning
@@ -279,13 +295,15 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         wave_lds_sync();  // every lane has read Z before the buffer is reused
 
         const size_t row = static_cast<size_t>(sd.stft_base) + t;
-        float cmax = m512;
+        // column maximum on the bit patterns: magnitudes are non-negative, so unsigned integer order is
+        // float order and v_max3_u32 needs none of the NaN canonicalisation fmaxf drags in
+        unsigned cmax_bits = __float_as_uint(m512);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int k = lane + 64 * r;
             sM[k] = mlo[r];
             sM[1024 - k] = mhi[r];
-            cmax = fmaxf(cmax, fmaxf(mlo[r], mhi[r]));
+            cmax_bits = max(cmax_bits, max(__float_as_uint(mlo[r]), __float_as_uint(mhi[r])));
         }
         if (lane == 0) sM[512] = m512;
         wave_lds_sync();
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         // maxima and compacts their bin numbers into LDS; pass 2 gives each lane one peak, so the
         // double-precision interpolation runs once per 64 peaks instead of once per bin stripe.
         if (want_chroma) {
-            cmax = wave_max(cmax);
+            const float cmax = __uint_as_float(wave_max_bits(cmax_bits));
             const float ref = 0.1f * cmax;
             int* cand = reinterpret_cast<int*>(fbuf + 1032);   // behind sM
             int base = 0;
