@@ -147,6 +147,26 @@ def test_long_single_segments(engine, flags):
     assert_features_close(got, want)
 
 
+def test_more_segments_than_one_launch_holds(engine, flags):
+    """70 000 overlapping windows in one call: more segments than a grid's y dimension (65 535), so the
+    library cuts chunks; fast path (2100 samples) and generic path (700 samples).  Rows must equal
+    the same windows featurised on their own (bit-exact: results do not depend on the batch)."""
+    rng = np.random.default_rng(70)
+    x = rng.standard_normal(300000).astype(np.float32)
+    x /= np.abs(x).max()
+    n = 70000
+    offs = (np.arange(n, dtype=np.int64) * 4) % (x.size - 2100)
+    for length in (2100, 700):
+        lens = np.full(n, length, dtype=np.int64)
+        got = engine.features(x, offs, lens, SR, flags).cpu().numpy()
+        assert got.shape == (n, 187) and np.isfinite(got).all()
+        pick = np.asarray([0, 1, 65534, 65535, 65536, 69999, 31337])
+        alone = engine.features(x, offs[pick], lens[pick], SR, flags).cpu().numpy()
+        np.testing.assert_array_equal(got[pick], alone)
+        want, _ = oracle_rows(x, offs[pick[:3]], lens[pick[:3]])
+        assert_features_close(got[pick[:3]], want)
+
+
 def test_silence_and_constant(engine, flags):
     z = np.zeros(9000, np.float32)
     got, tun = gpu_rows(engine, flags, z, [0, 100], [9000, 1000])
