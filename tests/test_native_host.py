@@ -127,3 +127,21 @@ def test_fft_lane_mapping_emulation():
         X[1024 - k] = np.conj(0.5 * (e2 - t2))
     X[512] = np.conj(buf[512 + 8])
     np.testing.assert_allclose(X, np.fft.rfft(x), atol=1e-10)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/serhip.h is the drop-in boundary: it must compile as C99 (extern "C" guards, stdint types,
+    no C++ or torch types) so cgo / JNI / ctypes-style bindings can consume it."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    header = Path(__file__).resolve().parent.parent / "include" / "serhip.h"
+    src = tmp_path / "use.c"
+    src.write_text('#include "serhip.h"\nint main(void) { return serhip_version() > 0 ? 0 : 1; }\n')
+    res = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src),
+                          "-I", str(header.parent), "-o", str(tmp_path / "use.o")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
