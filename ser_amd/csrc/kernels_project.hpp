@@ -17,10 +17,6 @@
 
 #include "kernels_fast.hpp"
 
-#ifndef SERHIP_EXP
-#define SERHIP_EXP 0
-#endif
-
 namespace serhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
