@@ -30,6 +30,24 @@ def shard_range(n_items: int, rank: int, world_size: int) -> tuple[int, int]:
     return int(b[rank]), int(b[rank + 1])
 
 
+def all_gather_rows_async(local, n_total: int, *, group=None):
+    """Non-blocking form for evenly divisible shards: returns ``(full, work)``; ``full`` is valid after
+    ``work.wait()`` (``work`` is None when nothing is in flight: single process, or uneven shards, which
+    take the blocking path because their padding rows have to be cut out afterwards)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return all_gather_rows(local, n_total, group=group), None
+    world = dist.get_world_size(group)
+    if int(local.shape[0]) * world != int(n_total):
+        return all_gather_rows(local, n_total, group=group), None
+    send = local.contiguous()
+    full = torch.empty((int(n_total), int(local.shape[1])), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(full, send, group=group, async_op=True)
+    return full, work
+
+
 def all_gather_rows(local, n_total: int, *, group=None):
     """Gather row shards ``[rows_r, D]`` (torch tensors, same device/dtype on all ranks) into
     the full ``[n_total, D]`` matrix on every rank, in rank order.

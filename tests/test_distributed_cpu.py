@@ -36,6 +36,13 @@ def _worker(rank, world, port, n_total, dim, result_dir):
     lo, hi = shard_range(n_total, rank, world)
     gathered = all_gather_rows(full[lo:hi].clone(), n_total)
     ok = torch.equal(gathered, full)
+    # the non-blocking form: even shards give a work handle, uneven ones fall back to the blocking path
+    from ser_amd.distributed import all_gather_rows_async
+
+    g2, work = all_gather_rows_async(full[lo:hi].clone(), n_total)
+    if work is not None:
+        work.wait()
+    ok = ok and torch.equal(g2, full) and ((work is not None) == ((hi - lo) * world == n_total))
     with open(os.path.join(result_dir, f"rank{rank}.txt"), "w") as f:
         f.write("ok" if ok else "mismatch")
     dist.destroy_process_group()
@@ -60,6 +67,10 @@ def test_all_gather_single_process_passthrough():
 
     x = torch.ones((4, 3))
     assert all_gather_rows(x, 4) is x
+    from ser_amd.distributed import all_gather_rows_async
+
+    full, work = all_gather_rows_async(x, 4)
+    assert full is x and work is None
     with pytest.raises(ValueError):
         all_gather_rows(x, 5)
     assert np.asarray(x).shape == (4, 3)
