@@ -18,18 +18,23 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #if defined(__HIP_DEVICE_COMPILE__)
 // gfx950 forms: the packed-f32 source modifiers (op_sel / neg_lo / neg_hi) give a complex multiply in
 // two instructions and a +-i rotation folded into an add, which the compiler does not find by itself
-// (it builds the swizzled, half-negated operand with v_xor + v_mov first).  Each asm statement is one
-// VALU instruction whose result is consumed by compiler-generated VALU code.
+// (it builds the swizzled, half-negated operand with v_xor + v_mov first).  The two instructions of a
+// complex multiply sit in ONE asm statement: around every asm statement the compiler assumes the worst
+// hazard and pads with s_nop when a neighbour touches the same registers.
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) {
-    v2f t;   // (-a.y*b.y, a.y*b.x)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    return __builtin_elementwise_fma(__builtin_shufflevector(a, a, 0, 0), b, t);
+    v2f t;   // (-a.y*b.y, a.y*b.x), then a.x * b + t
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"
+        : "=&v"(t) : "v"(a), "v"(b));
+    return t;
 }
 // b wave-uniform (a compile-time twiddle): kept in a scalar register pair, no VGPRs spent on constants
 __device__ __forceinline__ v2f cmul_uniform(v2f a, v2f b) {
     v2f t;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "s"(b));
-    return __builtin_elementwise_fma(__builtin_shufflevector(a, a, 0, 0), b, t);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"
+        : "=&v"(t) : "v"(a), "s"(b));
+    return t;
 }
 __device__ __forceinline__ v2f add_neg_i(v2f a, v2f b) {   // a + (-i) b = (a.x + b.y, a.y - b.x)
     v2f r;

@@ -23,15 +23,14 @@ namespace serhip {
 #ifndef SERHIP_K1_WAVES
 #define SERHIP_K1_WAVES 16
 #endif
-#ifndef SERHIP_K1_PREFETCH
-#define SERHIP_K1_PREFETCH 0   // 1: request the next frame's samples before this frame's unpack / stores / peaks
-                               // (needs > 128 VGPRs: measured no faster at 12 waves, spills at 16)
+#ifndef SERHIP_K1_OPAQUE_LANE
+#define SERHIP_K1_OPAQUE_LANE 1
 #endif
 // k_stft_frames runs ONE workgroup per CU: its waves share the 21 KB of twiddle/window tables in LDS and
 // each owns an 8.5 KB transpose buffer.  16 waves = 4 per SIMD at <= 128 VGPRs fill the 160 KB of LDS;
 // measured on MI355X (12.5k clips): 8 waves 4.2 ms, 12 waves 2.9 ms, 16 waves 2.8 ms.
 constexpr int kWaves = SERHIP_K1_WAVES; // waves per workgroup in k_stft_frames
-constexpr int kFramesPerBlock = 8 * kWaves;   // STFT frames per workgroup
+constexpr int kUnitFramesMax = 128;    // STFT frames per work unit of k_stft_frames (small calls use less)
 constexpr int kBufC = 1088;            // complex slots of one wave's LDS buffer (16 rows x stride 68)
 constexpr int kGroups = 65;            // 16-bin groups covering bins 0..1039 (1025 used)
 constexpr int kPeakLdsCap = 2048;      // peaks staged in LDS by k_segment_finish
@@ -46,6 +45,14 @@ struct SegDesc {
     int n_mel;            // mel-STFT columns (hop 512)
     int stft_base;        // first row in the magnitude / peak scratch
     int mel_base;         // first row in the mel scratch
+};
+
+// work unit of k_stft_frames: frames [t_begin, min(t_begin + unit_frames, n_stft)) of segment seg.  The
+// kernel is persistent: workgroup b walks units b, b + gridDim.x, ... and its waves take every kWaves-th
+// frame of the concatenation of those units, each at its own pace (no workgroup barrier after set-up).
+struct WorkUnit {
+    int seg;              // index into the chunk's descriptor array
+    int t_begin;
 };
 
 // constant tables of one plan (device pointers)
@@ -81,13 +88,20 @@ struct Scratch {
 };
 
 // Fast-path magnitudes are stored in the order k_project_frames consumes them: frame slots in tiles of
-// 16, and inside a tile [group of 16 bins][frame][16 bins], so that the A operand of one MFMA group is
-// one contiguous 1 KB block.  Returns the float4 index of bins 4q..4q+3 of frame slot f.  Every
-// segment starts on a tile boundary (the host pads stft_base to a multiple of 16).
-constexpr int kTileBytes = kGroups * 1024;   // 66 560 B per 16 frames
+// 16, and inside a tile [block of 32 bins][frame][32 bins].  One frame owns whole 128-byte lines (a
+// [16 bins]-per-frame layout would share every line between two frames, i.e. two waves of
+// k_stft_frames: measured, the half-line stores bound that kernel at 1.9 TB/s), and the A operands of
+// an even/odd pair of MFMA groups are the two interleaved halves of one 2 KB block.  Returns the float4
+// index of bins 4q..4q+3 of frame slot f.  Every segment starts on a tile boundary (the host pads
+// stft_base to a multiple of 16).
+constexpr int kPairBlocks = (kGroups + 1) / 2;          // 33 blocks of 32 bins (the last one half used)
+constexpr int kTileF4 = kPairBlocks * 128;              // float4 slots per 16-frame tile
+constexpr int kTileBytes = kTileF4 * 16;                // 67 584 B per 16 frames
 __host__ __device__ __forceinline__ size_t mags_tile_index(size_t f, int q) {
-    return ((f >> 4) * kGroups + static_cast<size_t>(q >> 2)) * 64 + (f & 15) * 4 + (q & 3);
+    return (f >> 4) * kTileF4 + static_cast<size_t>(q >> 3) * 128 + (f & 15) * 8 + (q & 7);
 }
+// float4 offset, inside a tile, of MFMA group G (16 bins) for lane (frame 0, kk 0)
+__host__ __device__ __forceinline__ int mags_group_offset(int G) { return (G >> 1) * 128 + (G & 1) * 4; }
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
@@ -164,7 +178,8 @@ __device__ __forceinline__ v2f piptrack_peak(float sm, float s0, float sp, int i
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __restrict__ audio,
                                                              const SegDesc* __restrict__ segs,
-                                                             PlanTables tb, Scratch sc) {
+                                                             const WorkUnit* __restrict__ units, int n_units,
+                                                             int unit_frames, PlanTables tb, Scratch sc) {
     __shared__ v2f s_twA[16 * 64];
     __shared__ v2f s_twU[8 * 64];
     __shared__ v2f s_win[16 * 64];
@@ -173,10 +188,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const SegDesc sd = segs[blockIdx.y];
-    const int t_begin = blockIdx.x * kFramesPerBlock;
-    if (t_begin >= sd.n_stft) return;  // whole workgroup leaves before any barrier
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the unit cursor below is scalar
 
     for (int i = tid; i < 16 * 64; i += kWaves * 64) {
         s_twA[i] = tb.twA[i];
@@ -190,8 +202,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     float* fbuf = reinterpret_cast<float*>(buf);
     float* sM = fbuf;            // |X|, bins 0..1024, natural order
 
-    const float* seg_audio = audio + sd.offset;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(seg_audio) & 7u) == 0);
     const int q = lane & 3;
     const float sg1 = (q & 2) ? -1.0f : 1.0f;
     const float sg2 = (q & 1) ? -1.0f : 1.0f;
@@ -201,11 +211,37 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     const bool want_chroma = (tb.flags & 2u) != 0;
     const bool want_proj = (tb.flags & 7u) != 0;   // any of mfcc / chroma / mel needs the magnitudes
 
-    const int t_end = min(t_begin + kFramesPerBlock, sd.n_stft);
+    // ---- cursor over this workgroup's units (wave-uniform, scalar registers).  `pos` is this wave's
+    // position in the concatenation of the workgroup's units, `base` the position of the current
+    // unit's first frame, `n` its frame count.
+    int u = blockIdx.x;           // the host launches at most n_units workgroups
+    WorkUnit wu = units[u];
+    SegDesc sd = segs[wu.seg];
+    int n = min(unit_frames, sd.n_stft - wu.t_begin);
+    int base = 0, pos = wave;
+    auto seek = [&]() -> bool {   // move to the unit that holds `pos`; false when the units are used up
+        while (pos >= base + n) {
+            base += n;
+            u += gridDim.x;
+            if (u >= n_units) return false;
+            wu = units[u];
+            sd = segs[wu.seg];
+            n = min(unit_frames, sd.n_stft - wu.t_begin);
+        }
+        return true;
+    };
     // frame t covers segment samples [t*512 - 1024, t*512 + 1024); lane l holds the 16 sample
     // pairs 128*n1 + 2*l.  Out-of-range samples are the zero padding of librosa.stft(center=True).
-    auto load_frame = [&](int t, v2f (&dst)[16]) {
+    auto load_frame = [&, lane_outer = lane](int t, v2f (&dst)[16]) {
+#if SERHIP_K1_OPAQUE_LANE
+        int lane = lane_outer;
+        asm volatile("" : "+v"(lane));
+#else
+        const int lane = lane_outer;
+#endif
         const int fs = t * kHop - kNfft / 2;   // < 2^31: the host rejects longer segments
+        const float* seg_audio = audio + sd.offset;
+        const bool aligned = ((reinterpret_cast<uintptr_t>(seg_audio) & 7u) == 0);
         if (fs >= 0 && fs + kNfft <= sd.len) {
             const float* p = seg_audio + fs + 2 * lane;
             if (aligned) {
@@ -255,22 +291,39 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
 
         // ---- stage B: 16-pt DFT over m1, twiddle W_64^(m2*j1), radix-4 across the quad
         fft16(v);
+        // two j1 chains are written interleaved: a DPP move needs two independent instructions between it
+        // and the VALU write of its source, and the compiler pads with s_nop what the source order does
+        // not give it (the kernel is bound by instruction issue: every s_nop costs a slot)
 #pragma unroll
-        for (int j1 = 0; j1 < 16; ++j1) {
-            v2f x = v[SERHIP_REV4(j1)];
-            if (j1 > 0) x = cmul(x, s_twB[j1 * 4 + q]);
-            const v2f p = v2f{dpp_mov<0x4E>(x.x), dpp_mov<0x4E>(x.y)};   // lane ^ 2
-            const v2f u = cmul(p + sg1 * x, rot3);
-            const v2f p2 = v2f{dpp_mov<0xB1>(u.x), dpp_mov<0xB1>(u.y)};  // lane ^ 1
-            const v2f w = p2 + sg2 * u;
+        for (int j1 = 0; j1 < 16; j1 += 2) {
+            v2f xa = v[SERHIP_REV4(j1)], xb = v[SERHIP_REV4(j1 + 1)];
+            if (j1 > 0) xa = cmul(xa, s_twB[j1 * 4 + q]);
+            xb = cmul(xb, s_twB[(j1 + 1) * 4 + q]);
+            const v2f pa = v2f{dpp_mov<0x4E>(xa.x), dpp_mov<0x4E>(xa.y)};   // lane ^ 2
+            const v2f pb = v2f{dpp_mov<0x4E>(xb.x), dpp_mov<0x4E>(xb.y)};
+            const v2f ta = pa + sg1 * xa;
+            const v2f tb2 = pb + sg1 * xb;
+            const v2f ua = cmul(ta, rot3);
+            const v2f ub = cmul(tb2, rot3);
+            const v2f qa = v2f{dpp_mov<0xB1>(ua.x), dpp_mov<0xB1>(ua.y)};   // lane ^ 1
+            const v2f qb = v2f{dpp_mov<0xB1>(ub.x), dpp_mov<0xB1>(ub.y)};
             // Z[k], k = k1 + 16*j1 + 256*j2, stored at k + 4*(k>>8)
-            buf[k1b + 16 * j1 + 260 * j2] = w;
+            buf[k1b + 16 * j1 + 260 * j2] = qa + sg2 * ua;
+            buf[k1b + 16 * (j1 + 1) + 260 * j2] = qb + sg2 * ub;
         }
         wave_lds_sync();
     };
     // second half of a frame: Z (in this wave's LDS buffer) -> |X|, stores, peaks.  Needs no registers
     // of the transform, so the next frame's samples are requested before it starts.
-    auto finish_frame = [&](int t) {
+    auto finish_frame = [&, lane_outer = lane](size_t row) {
+#if SERHIP_K1_OPAQUE_LANE
+        // an opaque copy of the lane id: the addresses derived from it are recomputed per frame instead of
+        // being hoisted out of the frame loop into ~40 VGPRs that the transform needs
+        int lane = lane_outer;
+        asm volatile("" : "+v"(lane));
+#else
+        const int lane = lane_outer;
+#endif
         // ---- real-FFT unpack: bins k = lane + 64r and 1024 - k from Z[k], Z[1024-k]
         float mlo[8], mhi[8];
 #pragma unroll
@@ -294,7 +347,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         }
         wave_lds_sync();  // every lane has read Z before the buffer is reused
 
-        const size_t row = static_cast<size_t>(sd.stft_base) + t;
         // column maximum on the bit patterns: magnitudes are non-negative, so unsigned integer order is
         // float order and v_max3_u32 needs none of the NaN canonicalisation fmaxf drags in
         unsigned cmax_bits = __float_as_uint(m512);
@@ -309,8 +361,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         wave_lds_sync();
 
         // ---- magnitudes for k_project_frames: a linear copy of sM, float4 chunk (lane + 64u) per lane
-        // (conflict-free ds_read_b128, 1 KB contiguous per store instruction); bin 1024 is stored with
-        // three zero pads so the last 16-bin group reads defined values
+        // (conflict-free ds_read_b128; eight whole 128-byte lines per store instruction); bin 1024 is
+        // stored with three zero pads so the last 16-bin group reads defined values
         if (want_proj) {
             const float4* mp = reinterpret_cast<const float4*>(sM);
             float4* m4 = reinterpret_cast<float4*>(sc.mags);
@@ -355,20 +407,19 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
     };
 
-    // The samples of frame t + kWaves are loaded into the registers frame t's transform has just
-    // released, ahead of frame t's stores: the loads are older than the stores in the vmcnt queue, so
-    // the next transform waits for its samples only, not for the write-back of this frame.
+    // The next frame's samples are requested after this frame's stores.  Requesting them earlier (into
+    // the registers the transform has released, ahead of the stores in the vmcnt queue) was measured
+    // twice, spill-free, and is 2-3 % slower: the waves do not wait on these loads.
     v2f v[16];
-    if (t_begin + wave < t_end) load_frame(t_begin + wave, v);
-    for (int t = t_begin + wave; t < t_end; t += kWaves) {
+    bool more = seek();
+    if (more) load_frame(wu.t_begin + (pos - base), v);
+    while (more) {
+        const size_t row = static_cast<size_t>(sd.stft_base) + static_cast<size_t>(wu.t_begin + (pos - base));
         transform_frame(v);
-#if SERHIP_K1_PREFETCH
-        load_frame(min(t + kWaves, t_end - 1), v);   // unconditional (the last one is a harmless re-read)
-        finish_frame(t);
-#else
-        finish_frame(t);
-        if (t + kWaves < t_end) load_frame(t + kWaves, v);
-#endif
+        finish_frame(row);
+        pos += kWaves;
+        more = seek();
+        if (more) load_frame(wu.t_begin + (pos - base), v);
     }
 }
 

@@ -51,15 +51,16 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     const bool active = t0 < sd.n_stft;   // a wave without a tile still fetches B rows and joins the barriers
     const bool want_chroma = (tb.flags & 2u) != 0, want_mel = (tb.flags & 5u) != 0;
     const int i = lane & 15, kk = lane >> 4;
-    // A operands: the two 16-frame tiles of this wave; group G of a tile is the 1 KB block at float4
-    // index G*64 and lane (frame i, kk) takes float4 i*4 + kk of it (one fully coalesced 1 KB read).  Frame
+    // A operands: the two 16-frame tiles of this wave; group G of a tile starts at float4 index
+    // mags_group_offset(G) and lane (frame i, kk) takes float4 i*8 + kk from there: an even group and the
+    // odd one after it are the two halves of the same sixteen 128-byte lines (see mags_tile_index).  Frame
     // slots past the segment's end inside a tile were never written: their rows of C are garbage and are
     // not stored.  A second tile that lies wholly past the end is replaced by the first; a wave without a
     // tile reads the workgroup's first tile and discards it.  Every wave issues the same three loads per
     // group, unconditionally: the waits in the loop are then exact vmcnt(n) counts and the prefetch holds.
     const size_t f0 = static_cast<size_t>(sd.stft_base) + (active ? t0 : blockIdx.x * kProjWaves * kProjTile);
-    const float4* a0p = reinterpret_cast<const float4*>(sc.mags) + (f0 >> 4) * kGroups * 64 + i * 4 + kk;
-    const float4* a1p = (active && t0 + 16 < sd.n_stft) ? a0p + kGroups * 64 : a0p;
+    const float4* a0p = reinterpret_cast<const float4*>(sc.mags) + (f0 >> 4) * kTileF4 + i * 8 + kk;
+    const float4* a1p = (active && t0 + 16 < sd.n_stft) ? a0p + kTileF4 : a0p;
     const float4* cb = tb.chroma_b + (want_chroma ? static_cast<size_t>(sc.tuning_idx[blockIdx.y]) * kGroups * 64 : 0) + lane;
     const float4* mb = tb.mel_b + lane;
     float* mel_out = sc.mel + (static_cast<size_t>(sd.mel_base) + t0 + 4 * kk) * kMels + i;
@@ -149,37 +150,46 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
         }
     };
 
-    // Software pipeline over two register sets (E for even groups, O for odd), no register copies:
-    // step G requests the B row of G + 2 first, multiplies group G, stores the B row of G + 1 (requested
-    // a step ago) to LDS and then requests the A rows of G + 2.
+    // Software pipeline over register sets, no register copies: E for even groups, O and P alternately
+    // for odd groups.  The even step G requests the B row of G + 2, multiplies group G, stores the B row
+    // of G + 1 (requested a step ago) to LDS and then requests the A rows of BOTH groups G + 2 and G + 3:
+    // they are the two halves of the same 128-byte lines, and requested back to back the second load
+    // finds the lines the first one brought (a step apart it found them evicted: +17 % kernel time).
     for (int j = threadIdx.x; j < kGroups; j += kProjWaves * 64) s_prog[j] = tb.mel_prog[j];
-    float4 aE0 = a0p[0], aE1 = a1p[0], aO0 = a0p[64], aO1 = a1p[64];
+    float4 aE0 = a0p[0], aE1 = a1p[0], aO0 = a0p[mags_group_offset(1)], aO1 = a1p[mags_group_offset(1)];
+    float4 aP0, aP1;
     __syncthreads();
     float4 bE = fetch_b(0, prog_at(0));
     float4 bO = fetch_b(1, prog_at(1));
     s_b[0][wave][lane] = bE;
     __syncthreads();
 
-#pragma unroll 1
-    for (int G = 0; G < kGroups - 1; G += 2) {
+    // one even + one odd step; the odd step consumes `ao*` and the even step refills `an*` (the other odd set)
+    auto pair_step = [&](int G, const float4& ao0, const float4& ao1, float4& an0, float4& an1) {
         // even group G: stage 0 holds its B rows
         bE = fetch_b(G + 2, prog_at(G + 2));            // G + 2 <= 64
         compute(G, aE0, aE1, prog_at(G));
         s_b[1][wave][lane] = bO;                        // B rows of G + 1
-        aE0 = a0p[(G + 2) * 64];
-        aE1 = a1p[(G + 2) * 64];
+        aE0 = a0p[mags_group_offset(G + 2)];
+        aE1 = a1p[mags_group_offset(G + 2)];
+        an0 = a0p[mags_group_offset(G + 3)];            // G + 3 = 65 at the end: the unused half of the last block
+        an1 = a1p[mags_group_offset(G + 3)];
         __syncthreads();
         // odd group G + 1: stage 1
-        const int G3 = min(G + 3, kGroups - 1);         // the last odd step re-reads group 64 (unused)
+        const int G3 = min(G + 3, kGroups - 1);         // the last odd step fetches a B row nobody uses
         bO = fetch_b(G3, prog_at(G3));
-        compute(G + 1, aO0, aO1, prog_at(G + 1));
+        compute(G + 1, ao0, ao1, prog_at(G + 1));
         s_b[0][wave][lane] = bE;                        // B rows of G + 2
-        aO0 = a0p[G3 * 64];
-        aO1 = a1p[G3 * 64];
         __syncthreads();
+    };
+    static_assert((kGroups - 1) % 4 == 0, "the loop below takes four groups per trip");
+#pragma unroll 1
+    for (int G = 0; G < kGroups - 1; G += 4) {
+        pair_step(G, aO0, aO1, aP0, aP1);
+        pair_step(G + 2, aP0, aP1, aO0, aO1);
     }
     // group 64 (kGroups is odd) holds only bin 1024 and three zero pads, in the kk = 0 chunk; the other
-    // chunks of that 1 KB block were never written
+    // chunks of that group were never written
     if (kk != 0) aE0 = aE1 = zero4;
     compute(kGroups - 1, aE0, aE1, prog_at(kGroups - 1));
     if (active && want_mel)

@@ -142,6 +142,7 @@ struct serhip_ctx {
     size_t staging_bytes = 0;
     hipEvent_t staging_done = nullptr;
     size_t chunk_frames = 0;     // frames of scratch per chunk (0 = default)
+    int cu_count = 256;          // compute units: grid size of the persistent k_stft_frames
     void* whisper_blob[2] = {nullptr, nullptr};   // tables for n_mels 80 / 128
     WhisperTables whisper_tb[2] = {};
     // optional per-kernel timing with HIP events (serhip_profile_*)
@@ -385,6 +386,13 @@ int serhip_create(int device_id, serhip_ctx** out) {
         delete ctx;
         return fail(SERHIP_E_HIP, "serhip_create: hipEventCreate failed");
     }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+            ctx->cu_count = cus;
+        else
+            (void)hipGetLastError();
+    }
     if (const char* env = std::getenv("SERHIP_CHUNK_FRAMES")) {
         const long long v = std::atoll(env);
         if (v > 0) ctx->chunk_frames = static_cast<size_t>(v);
@@ -554,6 +562,8 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
         int64_t first, count;    // range in the descriptor array
         int max_frames;
         bool generic;
+        size_t first_unit = 0, n_units = 0;   // fast chunks: range in the work-unit array
+        int unit_frames = kUnitFramesMax;
     };
     std::vector<SegDesc> descs;
     descs.reserve(static_cast<size_t>(n_seg));
@@ -630,8 +640,27 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
         }
     }
 
-    // ---- workspace: [descriptors | fast scratch | generic scratch]
-    const size_t desc_bytes = align_up(descs.size() * sizeof(SegDesc), 256);
+    // ---- work units of k_stft_frames: slices of the fast segments, chunk by chunk.  128 frames per unit
+    // when there is work for every CU; a small call (one recording, a few windows) is cut finer, down to
+    // 16 frames, so that it spreads over the chip instead of queueing on a few workgroups.
+    std::vector<WorkUnit> units;
+    for (Chunk& c : chunks) {
+        if (c.generic) continue;
+        size_t frames = 0;
+        for (int64_t i = 0; i < c.count; ++i) frames += static_cast<size_t>(descs[static_cast<size_t>(c.first + i)].n_stft);
+        const size_t share = (frames + ctx->cu_count - 1) / static_cast<size_t>(ctx->cu_count);
+        c.unit_frames = static_cast<int>(std::min<size_t>(kUnitFramesMax, std::max<size_t>(16, (share + 15) / 16 * 16)));
+        c.first_unit = units.size();
+        for (int64_t i = 0; i < c.count; ++i) {
+            const int n_stft = descs[static_cast<size_t>(c.first + i)].n_stft;
+            for (int t0 = 0; t0 < n_stft; t0 += c.unit_frames) units.push_back(WorkUnit{static_cast<int>(i), t0});
+        }
+        c.n_units = units.size() - c.first_unit;
+    }
+
+    // ---- workspace: [descriptors | work units | fast scratch | generic scratch]
+    const size_t seg_bytes = align_up(descs.size() * sizeof(SegDesc), 256);
+    const size_t desc_bytes = seg_bytes + align_up(units.size() * sizeof(WorkUnit), 256);
     size_t max_chunk_segs = 0;
     for (const Chunk& c : chunks)
         if (!c.generic) max_chunk_segs = std::max(max_chunk_segs, static_cast<size_t>(c.count));
@@ -639,12 +668,17 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
     const ScratchLayout lg = scratch_layout(std::max(gen_frames_max, gen_mel_max), kGenericPeakCap, 0);
     int rc = ensure_workspace(ctx, desc_bytes + lf.total + lg.total);
     if (rc != SERHIP_OK) return rc;
-    rc = ensure_staging(ctx, descs.size() * sizeof(SegDesc));
+    // descriptors and units travel in one copy: the staging buffer mirrors the head of the workspace
+    const size_t head_bytes = seg_bytes + units.size() * sizeof(WorkUnit);
+    rc = ensure_staging(ctx, head_bytes);
     if (rc != SERHIP_OK) return rc;
     std::memcpy(ctx->staging, descs.data(), descs.size() * sizeof(SegDesc));
+    if (!units.empty())
+        std::memcpy(static_cast<char*>(ctx->staging) + seg_bytes, units.data(), units.size() * sizeof(WorkUnit));
     char* ws = static_cast<char*>(ctx->ws);
     SegDesc* d_descs = reinterpret_cast<SegDesc*>(ws);
-    HIP_TRY(hipMemcpyAsync(d_descs, ctx->staging, descs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, stream));
+    const WorkUnit* d_units = reinterpret_cast<const WorkUnit*>(ws + seg_bytes);
+    HIP_TRY(hipMemcpyAsync(ws, ctx->staging, head_bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(ctx->staging_done, stream));
     const Scratch sf = scratch_at(ws + desc_bytes, lf, plan->peak_cap);
     const Scratch sg = scratch_at(ws + desc_bytes + lf.total, lg, kGenericPeakCap);
@@ -655,10 +689,11 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
     for (const Chunk& c : chunks) {
         const SegDesc* dd = d_descs + c.first;
         if (!c.generic) {
-            const dim3 grid((c.max_frames + kFramesPerBlock - 1) / kFramesPerBlock, static_cast<unsigned>(c.count));
-            {
+            {   // persistent: one workgroup per CU (its LDS footprint allows no more), never more than units
+                const unsigned wgs = static_cast<unsigned>(std::min<size_t>(c.n_units, static_cast<size_t>(ctx->cu_count)));
                 LaunchTimer lt(ctx, SERHIP_KERNEL_STFT_FRAMES, stream);
-                hipLaunchKernelGGL(k_stft_frames, grid, dim3(kWaves * 64), 0, stream, audio_dev, dd, plan->tb, sf);
+                hipLaunchKernelGGL(k_stft_frames, dim3(wgs), dim3(kWaves * 64), 0, stream, audio_dev, dd,
+                                   d_units + c.first_unit, static_cast<int>(c.n_units), c.unit_frames, plan->tb, sf);
             }
             const dim3 segs_grid(static_cast<unsigned>(c.count));
             if (want_chroma || tuning_dev) {   // tuning estimate per segment (zeros when chroma is off)
