@@ -48,8 +48,9 @@ struct SegDesc {
 };
 
 // work unit of k_stft_frames: frames [t_begin, min(t_begin + unit_frames, n_stft)) of segment seg.  The
-// kernel is persistent: workgroup b walks units b, b + gridDim.x, ... and its waves take every kWaves-th
-// frame of the concatenation of those units, each at its own pace (no workgroup barrier after set-up).
+// kernel is persistent: workgroup b walks units b, b + gridDim.x, ... and its waves draw frame after
+// frame of the concatenation of those units from a counter in LDS (no workgroup barrier after set-up;
+// the frames in flight in a workgroup stay neighbours, so the 75 % they share is read from HBM once).
 struct WorkUnit {
     int seg;              // index into the chunk's descriptor array
     int t_begin;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     __shared__ v2f s_win[16 * 64];
     __shared__ v2f s_twB[16 * 4];
     __shared__ __attribute__((aligned(16))) v2f s_buf[kWaves][kBufC];
+    __shared__ int s_next;   // next undrawn position in the concatenation of this workgroup's units
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     }
     for (int i = tid; i < 8 * 64; i += kWaves * 64) s_twU[i] = tb.twU[i];
     if (tid < 64) s_twB[tid] = tb.twB[tid];
+    if (tid == 0) s_next = 0;
     __syncthreads();
 
     v2f* buf = s_buf[wave];
@@ -212,13 +215,21 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     const bool want_proj = (tb.flags & 7u) != 0;   // any of mfcc / chroma / mel needs the magnitudes
 
     // ---- cursor over this workgroup's units (wave-uniform, scalar registers).  `pos` is this wave's
-    // position in the concatenation of the workgroup's units, `base` the position of the current
-    // unit's first frame, `n` its frame count.
+    // position in the concatenation of the workgroup's units (drawn from s_next, so it only grows),
+    // `base` the position of the current unit's first frame, `n` its frame count.
     int u = blockIdx.x;           // the host launches at most n_units workgroups
     WorkUnit wu = units[u];
     SegDesc sd = segs[wu.seg];
     int n = min(unit_frames, sd.n_stft - wu.t_begin);
-    int base = 0, pos = wave;
+    int base = 0;
+    // draw the next position; the value is read back (readfirstlane) only where it is needed, so the LDS
+    // round trip of the atomic hides behind the frame in hand
+    auto draw = [&]() {
+        int p = 0;
+        if (lane == 0) p = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return p;
+    };
+    int pos = __builtin_amdgcn_readfirstlane(draw());
     auto seek = [&]() -> bool {   // move to the unit that holds `pos`; false when the units are used up
         while (pos >= base + n) {
             base += n;
@@ -415,9 +426,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     if (more) load_frame(wu.t_begin + (pos - base), v);
     while (more) {
         const size_t row = static_cast<size_t>(sd.stft_base) + static_cast<size_t>(wu.t_begin + (pos - base));
+        const int drawn = draw();
         transform_frame(v);
         finish_frame(row);
-        pos += kWaves;
+        pos = __builtin_amdgcn_readfirstlane(drawn);
         more = seek();
         if (more) load_frame(wu.t_begin + (pos - base), v);
     }
