@@ -23,8 +23,14 @@ namespace serhip {
 #ifndef SERHIP_K1_WAVES
 #define SERHIP_K1_WAVES 16
 #endif
+// Opaque copies of the lane id stop the compiler from hoisting lane-derived addresses out of the frame
+// loop.  In the frame loader (whose zero-padding path holds 32 of them) that keeps the kernel spill-free;
+// in the second half of a frame the hoisted addresses fit and save ~40 VALU instructions per frame.
 #ifndef SERHIP_K1_OPAQUE_LANE
-#define SERHIP_K1_OPAQUE_LANE 1
+#define SERHIP_K1_OPAQUE_LANE 0
+#endif
+#ifndef SERHIP_K1_OPAQUE_LOAD
+#define SERHIP_K1_OPAQUE_LOAD 1
 #endif
 // k_stft_frames runs ONE workgroup per CU: its waves share the 21 KB of twiddle/window tables in LDS and
 // each owns an 8.5 KB transpose buffer.  16 waves = 4 per SIMD at <= 128 VGPRs fill the 160 KB of LDS;
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     // frame t covers segment samples [t*512 - 1024, t*512 + 1024); lane l holds the 16 sample
     // pairs 128*n1 + 2*l.  Out-of-range samples are the zero padding of librosa.stft(center=True).
     auto load_frame = [&, lane_outer = lane](int t, v2f (&dst)[16]) {
-#if SERHIP_K1_OPAQUE_LANE
+#if SERHIP_K1_OPAQUE_LOAD
         int lane = lane_outer;
         asm volatile("" : "+v"(lane));
 #else
