@@ -465,7 +465,7 @@ __device__ __forceinline__ float tuning_residual(float pitch) {
 }
 
 // histogram bin of np.histogram(residual, np.linspace(-0.5, 0.5, 101)): [e_i, e_i+1), last closed
-__device__ __forceinline__ int tuning_bin(float r, const double* __restrict__ edges) {
+__device__ __forceinline__ int tuning_bin(float r, const double* edges) {
     const double x = static_cast<double>(r);
     int i = static_cast<int>((x + 0.5) * 100.0);
     i = max(0, min(99, i));
@@ -487,6 +487,8 @@ struct FinishShared {
     double lsum[kMode == 2 ? 8 : 2][kMels];
     float chroma_acc[4][16];
     unsigned sel_prefix, sel_k;
+    unsigned sel_cnt, sel_cum;   // pass 0 of select_kth: keys in the selected bucket / in the buckets below it
+    double edges[kMode == 2 ? 1 : kTunings];   // histogram edges (a copy: two dependent reads per peak)
     int n_peaks;
     int tuning_idx;
     float thr;
@@ -499,11 +501,44 @@ __device__ __forceinline__ void for_each_peak(const Sh& sh, bool in_lds, const S
     if (in_lds) {
         for (int i = threadIdx.x; i < sh.n_peaks; i += blockDim.x) f(sh.peaks[i]);
     } else {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-        for (int t = wave; t < sd.n_stft; t += nw) {
-            const size_t row = static_cast<size_t>(sd.stft_base) + t;
-            const int c = sc.peak_cnt[row];
-            for (int j = lane; j < c; j += 64) f(sc.peaks[row * peak_cap + j]);
+        // Peaks that do not fit the LDS staging (noisy or long segments) are re-read from their rows in
+        // every pass.  Wave w owns rows w, w + nw, ...: one strided load brings the counts of 64 of its
+        // rows, then 4 rows x 4 chunks of 64 peaks are requested before the first one is consumed
+        // (a row-by-row walk with its two dependent loads per row was ~6x slower on white noise).
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int nw = blockDim.x >> 6;
+        for (int tb = wave; tb < sd.n_stft; tb += 64 * nw) {
+            const int my_t = tb + lane * nw;
+            const int my_cnt = my_t < sd.n_stft ? sc.peak_cnt[static_cast<size_t>(sd.stft_base) + my_t] : 0;
+            const int rows = min(64, (sd.n_stft - tb + nw - 1) / nw);
+            for (int r0 = 0; r0 < rows; r0 += 4) {
+                int c[4];
+                const v2f* prow[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // lanes past `rows` hold 0; r0 + u < 64 because rows <= 64 and r0 is a multiple of 4
+                    c[u] = __builtin_amdgcn_readlane(my_cnt, r0 + u);
+                    prow[u] = sc.peaks + (static_cast<size_t>(sd.stft_base) + tb + static_cast<size_t>(r0 + u) * nw) * peak_cap;
+                }
+                const int cmax = max(max(c[0], c[1]), max(c[2], c[3]));
+                for (int j0 = 0; j0 < cmax; j0 += 256) {
+                    v2f val[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int j = j0 + 64 * k + lane;
+                            if (j < c[u]) val[u][k] = prow[u][j];
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int j = j0 + 64 * k + lane;
+                            if (j < c[u]) f(val[u][k]);
+                        }
+                }
+            }
         }
     }
 }
@@ -511,11 +546,21 @@ __device__ __forceinline__ void for_each_peak(const Sh& sh, bool in_lds, const S
 // k-th smallest peak magnitude (0-based) by radix select on the order-preserving key, 11 + 11 + 10
 // bits (wide digits keep the LDS histogram atomics spread: peak magnitudes share few exponents).
 // All threads return it.  blockDim.x must be 256.
+//
+// Peaks that did not fit the LDS staging (in_lds false) are read from their rows in HBM.  After the
+// first digit only the keys of ONE bucket still matter: if that bucket fits, it is compacted into
+// sh.peaks by one more pass over the rows and the remaining digits (and below_threshold) run from LDS
+// -- three passes over HBM per segment (first digit, compaction, final histogram) instead of five.
+// Then *subset is set, sh.n_peaks is the bucket's size, and *lower_cnt / *lower_max describe the keys
+// of the lower buckets (their number, their largest magnitude).
 template <typename Sh>
 __device__ float select_kth(Sh& sh, bool in_lds, const Scratch& sc, const SegDesc& sd,
-                            int peak_cap, unsigned k) {
+                            int peak_cap, unsigned k, bool* subset, unsigned* lower_cnt, float* lower_max) {
     unsigned prefix = 0, mask = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    *subset = false;
+    *lower_cnt = 0;
+    *lower_max = -INFINITY;
     for (int pass = 0; pass < 3; ++pass) {
         const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
         const unsigned digit_mask = pass == 2 ? 1023u : 2047u;
@@ -563,11 +608,35 @@ __device__ float select_kth(Sh& sh, bool in_lds, const Scratch& sc, const SegDes
             }
             sh.sel_prefix = prefix | (static_cast<unsigned>(8 * tid + b) << shift);
             sh.sel_k = k - cum;
+            sh.sel_cnt = c[b];
+            sh.sel_cum = cum;
         }
         __syncthreads();
         prefix = sh.sel_prefix;
         k = sh.sel_k;
         mask |= digit_mask << shift;
+        if (pass == 0 && !in_lds && sh.sel_cnt <= static_cast<unsigned>(kPeakLdsCap)) {
+            *lower_cnt = sh.sel_cum;
+            __syncthreads();   // everyone has read sel_cnt / sel_cum
+            if (tid == 0) sh.n_peaks = 0;
+            __syncthreads();
+            float lmax = -INFINITY;
+            for_each_peak(sh, false, sc, sd, peak_cap, [&](v2f pm) {
+                const unsigned top = float_key(pm.y) & mask;
+                if (top == prefix) {
+                    sh.peaks[atomicAdd(&sh.n_peaks, 1)] = pm;
+                } else if (top < prefix) {
+                    lmax = fmaxf(lmax, pm.y);
+                }
+            });
+            lmax = wave_max(lmax);
+            if (lane == 0) sh.red[wave] = lmax;
+            __syncthreads();
+            *lower_max = fmaxf(fmaxf(sh.red[0], sh.red[1]), fmaxf(sh.red[2], sh.red[3]));
+            *subset = true;
+            in_lds = true;
+            __syncthreads();   // sh.red free again
+        }
     }
     return key_float(prefix);
 }
@@ -740,6 +809,9 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
 
     // ---- tuning estimate: median of peak magnitudes, histogram of residuals above it
     if (tid == 0) sh.n_peaks = 0;
+    if constexpr (kMode != 2) {
+        for (int i = tid; i < kTunings; i += blockDim.x) sh.edges[i] = tb.edges[i];
+    }
     __syncthreads();
     // per-frame counts: loaded in parallel; for segments of <= 1024 frames they are kept (sh.hist is
     // free until the select) so that the gather below needs no dependent global loads
@@ -827,20 +899,27 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
     }
     int tuning_idx = 50;  // edge 50 is exactly 0.0: librosa's answer for an empty peak set
     if (n_peaks > 0) {
-        float thr = select_kth(sh, in_lds, sc, sd, sc.peak_cap, static_cast<unsigned>(n_peaks / 2));
+        bool subset;
+        unsigned lower_cnt;
+        float lower_max;
+        float thr = select_kth(sh, in_lds, sc, sd, sc.peak_cap, static_cast<unsigned>(n_peaks / 2), &subset,
+                               &lower_cnt, &lower_max);
         if ((n_peaks & 1) == 0) {
             // the element of rank n/2 - 1: the largest value below thr if exactly n/2 values are below it,
-            // else thr itself (a tie)
+            // else thr itself (a tie).  With the selected bucket compacted into LDS, the keys of the
+            // lower buckets come in through their count and their maximum.
             int n_below;
             float below;
-            below_threshold(sh, in_lds, sc, sd, sc.peak_cap, thr, &n_below, &below);
+            below_threshold(sh, in_lds || subset, sc, sd, sc.peak_cap, thr, &n_below, &below);
+            n_below += static_cast<int>(lower_cnt);
+            below = fmaxf(below, lower_max);
             const float lo = (n_below == n_peaks / 2) ? below : thr;
             thr = (lo + thr) / 2.0f;  // np.median of an even count: f32 mean of the middle pair
         }
         for (int i = tid; i < 256; i += blockDim.x) sh.hist[i] = 0;
         __syncthreads();
         for_each_peak(sh, in_lds, sc, sd, sc.peak_cap, [&](v2f pm) {
-            if (pm.y >= thr && pm.x > 0.0f) atomicAdd(&sh.hist[tuning_bin(tuning_residual(pm.x), tb.edges)], 1u);
+            if (pm.y >= thr && pm.x > 0.0f) atomicAdd(&sh.hist[tuning_bin(tuning_residual(pm.x), sh.edges)], 1u);
         });
         __syncthreads();
         if (tid == 0) {

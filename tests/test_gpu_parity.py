@@ -147,6 +147,30 @@ def test_long_single_segments(engine, flags):
     assert_features_close(got, want)
 
 
+def test_dense_peaks_tuning_paths(engine, flags):
+    """3 s clips with thousands of piptrack peaks: too many for the tuning kernel's LDS staging, so the
+    median runs over the rows in HBM -- with the selected radix bucket compacted into LDS (harmonics in
+    noise) or, when even that bucket is too large, digit by digit from HBM (white noise)."""
+    from ser_amd.synth import harmonic_clip
+
+    rng = np.random.default_rng(77)
+    n = 3 * SR
+    clips = []
+    for noise_level in (0.3, 1.0, 0.0):
+        x = noise_level * rng.standard_normal(n).astype(np.float32)
+        if noise_level < 1.0:
+            x = x + harmonic_clip(rng, n, SR)
+        clips.append((x / np.abs(x).max()).astype(np.float32))
+    clips.append(clips[1][:2 * SR + 1])              # white noise, odd length (odd peak count likely differs)
+    audio = np.concatenate(clips)
+    offs = np.cumsum([0] + [len(c) for c in clips[:-1]]).tolist()
+    lens = [len(c) for c in clips]
+    got, tun = gpu_rows(engine, flags, audio, offs, lens)
+    want, wtun = oracle_rows(audio, offs, lens)
+    np.testing.assert_allclose(tun, wtun, atol=1e-6)
+    assert_features_close(got, want)
+
+
 def test_more_segments_than_one_launch_holds(engine, flags):
     """70 000 overlapping windows in one call: more segments than a grid's y dimension (65 535), so the
     library cuts chunks; fast path (2100 samples) and generic path (700 samples).  Rows must equal
