@@ -14,3 +14,7 @@ print("validate_signal      %.1f ms" % t(lambda: dsp.validate_signal(x, 16000)))
 print("to_device (pageable) %.1f ms" % t(lambda: eng.to_device(x)))
 b = HandcraftedBackend(feature_flags=FeatureFlags(tonnetz=False))
 print("encode_sequence      %.1f ms" % t(lambda: b.encode_sequence(x, 16000)))
+clips = [x[i * 48000:(i + 1) * 48000] for i in range(1200)]
+print("extract_vectors 1200 clips (230 MB)  %.1f ms" % t(lambda: b.extract_vectors(clips, 16000)))
+xp = torch.from_numpy(x).pin_memory()
+print("to_device (pinned)   %.1f ms" % t(lambda: xp.to(eng.device, non_blocking=True)))

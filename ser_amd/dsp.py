@@ -35,7 +35,9 @@ def validate_signal(audio: NDArray[np.float32], sample_rate: int) -> NDArray[np.
     if audio.size == 0:
         raise ValueError("Audio contains no samples.")
     prepared = np.asarray(audio, dtype=np.float32)
-    if not bool(np.all(np.isfinite(prepared))):
+    # a finite sum of squares proves every sample finite (NaN and inf propagate) in one BLAS pass without
+    # the boolean temporary of np.isfinite; an overflowing one falls through to the exact test
+    if not np.isfinite(np.dot(prepared, prepared)) and not bool(np.all(np.isfinite(prepared))):
         raise ValueError("Audio buffer is not finite everywhere.")
     return prepared
 

@@ -204,3 +204,23 @@ def test_product_never_imports_the_oracle():
     for path in list(root.rglob("*.py")) + list(root.rglob("*.hpp")) + list(root.rglob("*.hip")):
         text = path.read_text()
         assert "import oracle" not in text and "from oracle" not in text, path
+
+
+def test_validate_signal_messages_and_extreme_values():
+    """Input checks of dsp.py:85-95 (order and messages); huge but finite samples pass even though
+    their sum of squares overflows the fast finiteness test."""
+    from ser_amd.dsp import validate_signal
+
+    ok = np.array([1e30, -3e38, 0.5], dtype=np.float32)
+    assert validate_signal(ok, 16000) is not None
+    with pytest.raises(ValueError, match="Sample rate must be a positive integer."):
+        validate_signal(ok, 0)
+    with pytest.raises(ValueError, match="mono"):
+        validate_signal(np.zeros((2, 2), dtype=np.float32), 16000)
+    with pytest.raises(ValueError, match="no samples"):
+        validate_signal(np.zeros(0, dtype=np.float32), 16000)
+    for bad in (np.nan, np.inf, -np.inf):
+        x = np.zeros(1000, dtype=np.float32)
+        x[777] = bad
+        with pytest.raises(ValueError, match="not finite everywhere"):
+            validate_signal(x, 16000)
