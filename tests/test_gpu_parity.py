@@ -319,6 +319,30 @@ def test_extract_feature_from_signal_contract(engine):
     assert extract_feature_from_signal(x, SR, feature_flags=FeatureFlags(False, False, False, False, False)).shape == (0,)
 
 
+def test_repeated_plan_skips_descriptor_upload_safely(engine, flags):
+    """A call with the same segment plan as the one before reuses the descriptors already in the
+    workspace; any other use of the workspace in between (another plan, a pooling call) must force the
+    upload again.  Every variant has to give the same bits."""
+    from ser_amd import EncodedSequence, PoolingWindow, mean_std_pool
+    from ser_amd.synth import harmonic_clips
+
+    a1 = harmonic_clips(501, 8, 48000).reshape(-1)
+    a2 = harmonic_clips(502, 8, 48000).reshape(-1)
+    offs, lens = [i * 48000 for i in range(8)], [48000] * 8
+    other_offs, other_lens = [0, 1000], [30000, 2500]
+    first, _ = gpu_rows(engine, flags, a1, offs, lens)
+    hit, _ = gpu_rows(engine, flags, a2, offs, lens)                 # same plan: no upload
+    gpu_rows(engine, flags, a1, other_offs, other_lens)              # different plan
+    miss, _ = gpu_rows(engine, flags, a2, offs, lens)                # uploaded again
+    np.testing.assert_array_equal(hit, miss)
+    enc = EncodedSequence(miss.astype(np.float32), np.arange(8.0), np.arange(8.0) + 1.0, "handcrafted")
+    mean_std_pool(enc, [PoolingWindow(0.0, 4.0), PoolingWindow(2.0, 8.0)])   # overwrites the workspace head
+    after_pool, _ = gpu_rows(engine, flags, a2, offs, lens)
+    np.testing.assert_array_equal(after_pool, miss)
+    again, _ = gpu_rows(engine, flags, a1, offs, lens)               # same plan, other audio: hit
+    np.testing.assert_array_equal(again, first)
+
+
 def test_pooling_kernels_bit_exact(engine):
     """mean_std_pool / HandcraftedBackend.pool on the GPU equal numpy bit for bit."""
     from oracle import ser_fast_path as ofp
