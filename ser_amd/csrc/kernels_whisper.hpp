@@ -4,9 +4,8 @@
 // Slaney mel at 16 kHz / log10 / clamp to (clip max - 8) / (x + 4) / 4.
 //
 // 400 is not a power of two and may not be zero-padded (the bins would move), so each
-// frame is a 200-point complex DFT of the even/odd packed samples, done as a 25 x 8
-// two-step decomposition through LDS (sums of 25 and 8 terms, so float32 error stays
-// at FFT level), then the real-FFT unpack to 201 bins.
+// frame is a 200-point complex DFT of the even/odd packed samples, done as 5 x 5 x 8
+// through LDS in double precision, then the real-FFT unpack to 201 bins.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -26,6 +25,21 @@ constexpr int kWMelWCap = 1024;      // sparse mel taps (80 mels: ~400, 128 mels
 typedef double v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2d cmuld(v2d a, v2d b) {
     return v2d{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+
+// forward 5-point DFT in place (W_5 = exp(-2 pi i / 5)), the symmetric form: 16 complex additions and
+// 8 real-by-complex multiplications
+__device__ __forceinline__ void dft5(v2d (&x)[5]) {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;   // cos(2 pi/5), cos(4 pi/5)
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;    // sin(2 pi/5), sin(4 pi/5)
+    const v2d a1 = x[1] + x[4], b1 = x[1] - x[4], a2 = x[2] + x[3], b2 = x[2] - x[3];
+    const v2d m1 = x[0] + c1 * a1 + c2 * a2, m2 = x[0] + c2 * a1 + c1 * a2;
+    const v2d n1 = s1 * b1 + s2 * b2, n2 = s2 * b1 - s1 * b2;
+    x[0] = x[0] + a1 + a2;
+    x[1] = v2d{m1.x + n1.y, m1.y - n1.x};   // m1 - i n1
+    x[4] = v2d{m1.x - n1.y, m1.y + n1.x};   // m1 + i n1
+    x[2] = v2d{m2.x + n2.y, m2.y - n2.x};
+    x[3] = v2d{m2.x - n2.y, m2.y + n2.x};
 }
 
 struct WhisperTables {
@@ -90,61 +104,70 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
             }
         }
         wave_lds_sync();
-        // ---- step 1: Y[k1][n2] = sum_{n1<25} z[8 n1 + n2] W_25^(n1 k1), then * W_200^(n2 k1).
-        // Output o = lane + 64 i has n2 = lane & 7 for every i, so the four outputs of a lane share each
-        // z read; their twiddles W_25^(n1 k1) advance by a complex multiplication (double precision:
-        // 24 steps cost ~1e-15) instead of a table read.  LDS reads per lane: 25 + 8 instead of 200.
+        // ---- step 1: Y[k1][n2] = sum_{n1<25} z[8 n1 + n2] W_25^(n1 k1), then * W_200^(n2 k1): eight 25-point
+        // DFTs (one per n2), each as 5 x 5 Cooley-Tukey with n1 = 5 p + q, k1 = r + 5 s.  Lane (n2, q) takes
+        // the 5-point DFT over p and the twiddle W_25^(q r); lane (n2, r) then the 5-point DFT over q.
+        // 40 lanes, ~70 double-precision operations each per stage, against 25-term sums with a twiddle
+        // recurrence (~800 per lane) before.  The second stage works in place in y: a wave's LDS
+        // accesses complete in order, so every lane has read its inputs before any lane writes.
         {
-            const int n2 = lane & 7;
-            v2d acc[4], w[4], step[4];
+            const int n2 = lane & 7, q5 = lane >> 3;   // q5: q in the first stage, r in the second
+            if (lane < 40) {
+                v2d x[5];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k1 = min((lane >> 3) + 8 * i, 24);
-                acc[i] = v2d{0.0, 0.0};
-                w[i] = v2d{1.0, 0.0};
-                step[i] = s_tw200[(8 * k1) % kWHalf];   // W_25^k1
-            }
-            for (int n1 = 0; n1 < 25; ++n1) {
-                const v2d zz = z[8 * n1 + n2];
+                for (int p5 = 0; p5 < 5; ++p5) x[p5] = z[8 * (5 * p5 + q5) + n2];
+                dft5(x);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[i] += cmuld(zz, w[i]);
-                    w[i] = cmuld(w[i], step[i]);
+                for (int r = 0; r < 5; ++r) {
+                    const v2d a = r == 0 ? x[0] : cmuld(x[r], s_tw200[(8 * q5 * r) % kWHalf]);   // W_25^(q r)
+                    y[(r * 5 + q5) * 8 + n2] = a;
                 }
             }
+            wave_lds_sync();
+            if (lane < 40) {
+                v2d x[5];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int o = lane + 64 * i;
-                if (o < kWHalf) y[o] = cmuld(acc[i], s_tw200[n2 * (o >> 3)]);
+                for (int q = 0; q < 5; ++q) x[q] = y[(q5 * 5 + q) * 8 + n2];
+                dft5(x);
+#pragma unroll
+                for (int sgrp = 0; sgrp < 5; ++sgrp) {
+                    const int k1 = q5 + 5 * sgrp;
+                    y[k1 * 8 + n2] = cmuld(x[sgrp], s_tw200[n2 * k1]);   // n2 * k1 <= 168
+                }
             }
         }
         wave_lds_sync();
-        // ---- step 2: Z[k1 + 25 k2] = sum_{n2<8} Y'[k1][n2] W_8^(n2 k2).  Lane (k1, half) reads the 8
-        // values of its k1 once and produces k2 = 4 half + j, j = 0..3: W_8^(n2 k2) = W_8^(n2 j) (-1)^(n2 half),
-        // compile-time eighth roots of unity after the odd terms are negated for half = 1.
-        v2d zk[4];
-        const int k1s = lane % 25, half = lane / 25;
-        if (lane < 50) {
-            const double r = 0.70710678118654752440;
-            const v2d w8[8] = {v2d{1.0, 0.0}, v2d{r, -r}, v2d{0.0, -1.0}, v2d{-r, -r},
-                               v2d{-1.0, 0.0}, v2d{-r, r}, v2d{0.0, 1.0}, v2d{r, r}};
+        // ---- step 2: Z[k1 + 25 k2] = sum_{n2<8} Y'[k1][n2] W_8^(n2 k2): lane k1 < 25 reads its eight values
+        // (128 contiguous bytes) and takes a radix-2 x radix-4 FFT in registers (~60 operations; the
+        // 8-term sums with constant roots took 112 on each of 50 lanes).  z was last read in step 1.
+        if (lane < 25) {
+            const double rh = 0.70710678118654752440;
             v2d yy[8];
 #pragma unroll
-            for (int n2 = 0; n2 < 8; ++n2) {
-                yy[n2] = y[k1s * 8 + n2];
-                if ((n2 & 1) && half) yy[n2] = -yy[n2];
+            for (int n2 = 0; n2 < 8; ++n2) yy[n2] = y[lane * 8 + n2];
+            v2d e[4], o[4];
+            {
+                const v2d s0 = yy[0] + yy[4], d0 = yy[0] - yy[4], s1 = yy[2] + yy[6], t = yy[2] - yy[6];
+                e[0] = s0 + s1;
+                e[1] = v2d{d0.x + t.y, d0.y - t.x};   // d0 - i t
+                e[2] = s0 - s1;
+                e[3] = v2d{d0.x - t.y, d0.y + t.x};   // d0 + i t
+            }
+            {
+                const v2d s0 = yy[1] + yy[5], d0 = yy[1] - yy[5], s1 = yy[3] + yy[7], t = yy[3] - yy[7];
+                o[0] = s0 + s1;
+                const v2d o1 = v2d{d0.x + t.y, d0.y - t.x};
+                const v2d o2 = s0 - s1;
+                const v2d o3 = v2d{d0.x - t.y, d0.y + t.x};
+                o[1] = v2d{rh * (o1.x + o1.y), rh * (o1.y - o1.x)};     // * W_8^1 = (1 - i) / sqrt 2
+                o[2] = v2d{o2.y, -o2.x};                                // * W_8^2 = -i
+                o[3] = v2d{rh * (o3.y - o3.x), -rh * (o3.x + o3.y)};    // * W_8^3 = (-1 - i) / sqrt 2
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v2d acc = yy[0];
-#pragma unroll
-                for (int n2 = 1; n2 < 8; ++n2) acc += cmuld(yy[n2], w8[(n2 * j) & 7]);
-                zk[j] = acc;
+            for (int k2 = 0; k2 < 4; ++k2) {
+                z[lane + 25 * k2] = e[k2] + o[k2];
+                z[lane + 25 * (k2 + 4)] = e[k2] - o[k2];
             }
-        }
-        if (lane < 50) {   // z was last read in step 1, two barriers ago
-#pragma unroll
-            for (int j = 0; j < 4; ++j) z[k1s + 25 * (4 * half + j)] = zk[j];
         }
         wave_lds_sync();
         // ---- real-FFT unpack to bins 0..200 and |X|^2
