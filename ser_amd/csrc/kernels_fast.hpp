@@ -79,6 +79,7 @@ struct PlanTables {
     int kmin, kmax;       // piptrack bin range (inclusive) for n_fft 2048
     int sample_rate;
     unsigned flags;
+    float mel_wsum_max;   // largest row sum of the mel bank: mel power <= (largest |X|)^2 * mel_wsum_max
 };
 
 // per-chunk scratch (device pointers)
@@ -87,10 +88,13 @@ struct Scratch {
     float* mel;           // [frames][128]  generic path: mel power; fast path: mel power in dB (k_project_frames)
     float* mel_part;      // [frames/16][128]  fast path: mel power summed over the 16 frames of a tile
     float* mel_dbmax;     // [frames/16][8]    fast path: max dB per (tile, 16-filter block)
+    double* mel_dbsum;    // [frames/16][128]  fast path: dB values summed over the 16 frames of a tile
+    float* mel_dbmin;     // [frames/16][128]  fast path: smallest dB value of the tile
     v2f* peaks;           // [frames][peak_cap]  (pitch, mag)
     int* peak_cnt;        // [frames]
     float* chroma_norm;   // [frames][16]  per-frame inf-normalised chroma (classes 12..15 unused)
     int* tuning_idx;      // [segments of the chunk]
+    unsigned* seg_cmax;   // [segments of the chunk] bit pattern of the segment's largest |X| (atomicMax, zeroed per call)
     int peak_cap;         // peak slots per frame
 };
 
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     };
     // second half of a frame: Z (in this wave's LDS buffer) -> |X|, stores, peaks.  Needs no registers
     // of the transform, so the next frame's samples are requested before it starts.
-    auto finish_frame = [&, lane_outer = lane](size_t row) {
+    auto finish_frame = [&, lane_outer = lane](size_t row, int seg) {
 #if SERHIP_K1_OPAQUE_LANE
         // an opaque copy of the lane id: the addresses derived from it are recomputed per frame instead of
         // being hoisted out of the frame loop into ~40 VGPRs that the transform needs
@@ -391,8 +395,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         // ---- piptrack peaks (bins kmin..kmax), threshold 0.1 * column max.  Pass 1 finds the local
         // maxima and compacts their bin numbers into LDS; pass 2 gives each lane one peak, so the
         // double-precision interpolation runs once per 64 peaks instead of once per bin stripe.
+        // the segment's largest magnitude bounds its mel power from above: k_project_frames uses it to
+        // tell which dB rows can never be clipped by top_db and need not be stored
+        if (want_proj) {
+            cmax_bits = wave_max_bits(cmax_bits);
+            if (lane == 0) atomicMax(&sc.seg_cmax[seg], cmax_bits);
+        }
         if (want_chroma) {
-            const float cmax = __uint_as_float(wave_max_bits(cmax_bits));
+            const float cmax = __uint_as_float(cmax_bits);
             const float ref = 0.1f * cmax;
             int* cand = reinterpret_cast<int*>(fbuf + 1032);   // behind sM
             int base = 0;
@@ -433,8 +443,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     while (more) {
         const size_t row = static_cast<size_t>(sd.stft_base) + static_cast<size_t>(wu.t_begin + (pos - base));
         const int drawn = draw();
+        const int seg = wu.seg;
         transform_frame(v);
-        finish_frame(row);
+        finish_frame(row, seg);
         pos = __builtin_amdgcn_readfirstlane(drawn);
         more = seek();
         if (more) load_frame(wu.t_begin + (pos - base), v);
@@ -484,7 +495,7 @@ struct FinishShared {
     int ired[8];
     double lmean[kMels];
     double melsum[2][kMels];
-    double lsum[kMode == 2 ? 8 : 2][kMels];
+    double lsum[2][kMels];
     float chroma_acc[4][16];
     unsigned sel_prefix, sel_k;
     unsigned sel_cnt, sel_cum;   // pass 0 of select_kth: keys in the selected bucket / in the buckets below it
@@ -722,22 +733,28 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         lmax = fmaxf(fmaxf(sh.red[0], sh.red[1]), fmaxf(sh.red[2], sh.red[3]));
         const float floor_db = lmax - 80.0f;
         if constexpr (kMode == 2) {
-            // dB rows as float4: thread (4 filters, 1 of 8 frame phases) -> 12 wide loads per 94-frame clip
-            // instead of 47 narrow ones; the 8 partial sums per filter are combined in a fixed order
-            const int m4 = tid & 31, part = tid >> 5;
-            double l4[4] = {0.0, 0.0, 0.0, 0.0};
+            // sum over time of max(dB, floor).  k_project_frames left, per 16-frame tile and filter, the sum
+            // and the minimum of the dB values: a tile whose minimum reaches the floor contributes its sum
+            // as it is (nothing in it is clipped), and only the others -- silence, fades -- are re-read
+            // from the dB rows.  In the common case the rows are written but never read back.
+            double ls = 0.0;
             if (want_mfcc) {
-                const float4* mel4 = reinterpret_cast<const float4*>(mel);
-                for (int t = part; t < sd.n_mel; t += 8) {
-                    const float4 v = mel4[static_cast<size_t>(t) * 32 + m4];
-                    l4[0] += static_cast<double>(fmaxf(v.x, floor_db));
-                    l4[1] += static_cast<double>(fmaxf(v.y, floor_db));
-                    l4[2] += static_cast<double>(fmaxf(v.z, floor_db));
-                    l4[3] += static_cast<double>(fmaxf(v.w, floor_db));
+                const int n_tiles = (sd.n_mel + 15) >> 4;
+                const size_t tile0 = static_cast<size_t>(sd.mel_base) >> 4;
+                for (int tl = half; tl < n_tiles; tl += 2) {
+                    const size_t at = (tile0 + tl) * kMels + m;
+                    if (sc.mel_dbmin[at] >= floor_db) {
+                        ls += sc.mel_dbsum[at];
+                    } else {
+                        double part = 0.0;
+                        const int t_end = min(16 * tl + 16, sd.n_mel);
+                        for (int t = 16 * tl; t < t_end; ++t)
+                            part += static_cast<double>(fmaxf(mel[static_cast<size_t>(t) * kMels + m], floor_db));
+                        ls += part;
+                    }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sh.lsum[part][4 * m4 + j] = l4[j];
+            sh.lsum[half][m] = ls;
         } else {
             double ls = 0.0;
             if (want_mfcc) {
@@ -751,11 +768,7 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         __syncthreads();
         const double inv_t = 1.0 / static_cast<double>(sd.n_mel);
         if (tid < kMels) {
-            double lsum = sh.lsum[0][tid] + sh.lsum[1][tid];
-            if constexpr (kMode == 2) {
-#pragma unroll
-                for (int q = 2; q < 8; ++q) lsum += sh.lsum[q][tid];
-            }
+            const double lsum = sh.lsum[0][tid] + sh.lsum[1][tid];
             sh.lmean[tid] = lsum * inv_t;
             if (want_mel) orow[off_mel + tid] = static_cast<float>((sh.melsum[0][tid] + sh.melsum[1][tid]) * inv_t);
         }

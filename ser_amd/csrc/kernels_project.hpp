@@ -65,6 +65,13 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     const float4* mb = tb.mel_b + lane;
     float* mel_out = sc.mel + (static_cast<size_t>(sd.mel_base) + t0 + 4 * kk) * kMels + i;
 
+    // top_db clips dB values more than 80 below the segment's maximum.  That maximum is at most
+    // 10 log10(cmax^2 * mel_wsum_max) (cmax: the segment's largest |X|, from k_stft_frames), so a block
+    // of dB values that all lie within 80 dB of this bound can never be clipped: k_segment_finish<2> will
+    // take the tile's sum as it is and the rows need not be written.  The 0.01 dB cover the rounding of
+    // the f32 sums and of log10f (< 3e-4 dB).
+    const float cmax = __uint_as_float(sc.seg_cmax[blockIdx.y]);
+    const float store_below = 10.0f * log10f(fmaxf(1e-10f, cmax * cmax * tb.mel_wsum_max)) + 0.01f - 80.0f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
     f32x4 c0 = zero, c1 = zero;
@@ -82,21 +89,39 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
             const int tb0 = t0 + 16 * h;
             if (tb0 < sd.n_stft) {   // wave-uniform
                 const f32x4 v = h ? lo1 : lo0;
-                float psum = 0.0f, dmax = -INFINITY;
+                float psum = 0.0f, dmax = -INFINITY, dmin = INFINITY;
+                double dsum = 0.0;
+                float db[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    db[r] = 10.0f * log10f(fmaxf(1e-10f, v[r]));
                     if (tb0 + 4 * kk + r < sd.n_stft) {
-                        const float db = 10.0f * log10f(fmaxf(1e-10f, v[r]));
                         psum += v[r];
-                        dmax = fmaxf(dmax, db);
-                        mel_out[static_cast<size_t>(16 * h + r) * kMels + 16 * cur] = db;
+                        dsum += static_cast<double>(db[r]);
+                        dmax = fmaxf(dmax, db[r]);
+                        dmin = fminf(dmin, db[r]);
                     }
                 }
+                if (-wave_max(-dmin) < store_below) {   // wave-uniform: some value of this block may be clipped
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (tb0 + 4 * kk + r < sd.n_stft)
+                            mel_out[static_cast<size_t>(16 * h + r) * kMels + 16 * cur] = db[r];
+                }
+                // the four lanes (kk = 0..3) that hold one filter's 16 frames
                 psum += __shfl_xor(psum, 16);
                 psum += __shfl_xor(psum, 32);
+                dsum += __shfl_xor(dsum, 16);
+                dsum += __shfl_xor(dsum, 32);
+                dmin = fminf(dmin, __shfl_xor(dmin, 16));
+                dmin = fminf(dmin, __shfl_xor(dmin, 32));
                 dmax = wave_max(dmax);
                 const size_t tile = (f0 >> 4) + h;
-                if (kk == 0) sc.mel_part[tile * kMels + 16 * cur + i] = psum;
+                if (kk == 0) {
+                    sc.mel_part[tile * kMels + 16 * cur + i] = psum;
+                    sc.mel_dbsum[tile * kMels + 16 * cur + i] = dsum;
+                    sc.mel_dbmin[tile * kMels + 16 * cur + i] = dmin;
+                }
                 if (lane == 0) sc.mel_dbmax[tile * 8 + cur] = dmax;
             }
         }

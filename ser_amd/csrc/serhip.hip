@@ -212,7 +212,7 @@ int ensure_staging(serhip_ctx* ctx, size_t bytes) {
 }
 
 struct ScratchLayout {
-    size_t mags, mel, peaks, cnt, cnorm, tidx, mpart, mdbmax, total;
+    size_t mags, mel, peaks, cnt, cnorm, tidx, scmax, mpart, mdbmax, mdbsum, mdbmin, total;
 };
 ScratchLayout scratch_layout(size_t frames, int peak_cap, size_t segs) {
     ScratchLayout l{};
@@ -231,10 +231,16 @@ ScratchLayout scratch_layout(size_t frames, int peak_cap, size_t segs) {
     o = align_up(o + frames * 16 * sizeof(float), 256);
     l.tidx = o;
     o = align_up(o + segs * sizeof(int), 256);
+    l.scmax = o;
+    o = align_up(o + segs * sizeof(unsigned), 256);
     l.mpart = o;
     o = align_up(o + (frames + 15) / 16 * kMels * sizeof(float), 256);
     l.mdbmax = o;
     o = align_up(o + (frames + 15) / 16 * 8 * sizeof(float), 256);
+    l.mdbsum = o;
+    o = align_up(o + (frames + 15) / 16 * kMels * sizeof(double), 256);
+    l.mdbmin = o;
+    o = align_up(o + (frames + 15) / 16 * kMels * sizeof(float), 256);
     l.total = o;
     return l;
 }
@@ -246,8 +252,11 @@ Scratch scratch_at(char* base, const ScratchLayout& l, int peak_cap) {
     s.peak_cnt = reinterpret_cast<int*>(base + l.cnt);
     s.chroma_norm = reinterpret_cast<float*>(base + l.cnorm);
     s.tuning_idx = reinterpret_cast<int*>(base + l.tidx);
+    s.seg_cmax = reinterpret_cast<unsigned*>(base + l.scmax);
     s.mel_part = reinterpret_cast<float*>(base + l.mpart);
     s.mel_dbmax = reinterpret_cast<float*>(base + l.mdbmax);
+    s.mel_dbsum = reinterpret_cast<double*>(base + l.mdbsum);
+    s.mel_dbmin = reinterpret_cast<float*>(base + l.mdbmin);
     s.peak_cap = peak_cap;
     return s;
 }
@@ -530,6 +539,15 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
     tb.kmax = h.kmax;
     tb.sample_rate = sample_rate;
     tb.flags = feature_flags;
+    {
+        double wmax = 0.0;
+        for (int m = 0; m < kMels; ++m) {
+            double w = 0.0;
+            for (int k = 0; k < kBins; ++k) w += static_cast<double>(h.mel_dense[static_cast<size_t>(m) * kBins + k]);
+            wmax = std::max(wmax, w);
+        }
+        tb.mel_wsum_max = static_cast<float>(wmax * (1.0 + 1e-6));
+    }
     plan->peak_cap = std::max(8, (h.kmax - h.kmin + 2) / 2 + 2);
     *out = plan;
     return SERHIP_OK;
@@ -717,6 +735,7 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
     for (const Chunk& c : chunks) {
         const SegDesc* dd = d_descs + c.first;
         if (!c.generic) {
+            HIP_TRY(hipMemsetAsync(sf.seg_cmax, 0, static_cast<size_t>(c.count) * sizeof(unsigned), stream));
             {   // persistent: one workgroup per CU (its LDS footprint allows no more), never more than units
                 const unsigned wgs = static_cast<unsigned>(std::min<size_t>(c.n_units, static_cast<size_t>(ctx->cu_count)));
                 LaunchTimer lt(ctx, SERHIP_KERNEL_STFT_FRAMES, stream);

@@ -171,6 +171,38 @@ def test_dense_peaks_tuning_paths(engine, flags):
     assert_features_close(got, want)
 
 
+def test_top_db_clipping_paths(engine, flags):
+    """power_to_db(top_db=80) clips against the segment's maximum.  The projection kernel stores a block
+    of dB rows only if it might be clipped, and the reduction re-reads only tiles whose minimum is below
+    the floor: loud-then-faint clips (the switch inside a 16-frame tile, faint part 70 to 130 dB down),
+    a faint clip alone (nothing clipped, nothing stored) and digital silence after sound."""
+    from ser_amd.synth import harmonic_clip
+
+    rng = np.random.default_rng(91)
+    n = 3 * SR
+    loud = harmonic_clip(rng, n, SR)
+    clips = []
+    for gain in (3e-4, 1e-5, 3e-7):
+        x = loud.copy()
+        cut = 20000 + int(rng.integers(0, 5000))        # not on a tile boundary
+        x[cut:] = gain * rng.standard_normal(n - cut).astype(np.float32)
+        clips.append(x)
+    clips.append((1e-4 * rng.standard_normal(n)).astype(np.float32))
+    x = loud.copy()
+    x[30000:] = 0.0
+    clips.append(x)
+    audio = np.concatenate(clips)
+    offs = [i * n for i in range(len(clips))]
+    lens = [n] * len(clips)
+    got, tun = gpu_rows(engine, flags, audio, offs, lens)
+    want, wtun = oracle_rows(audio, offs, lens)
+    np.testing.assert_allclose(tun, wtun, atol=1e-6)
+    assert_features_close(got, want)
+    # the same clips one by one and in the reverse order: stale dB rows of other calls must never be read
+    back, _ = gpu_rows(engine, flags, audio, offs[::-1], lens)
+    np.testing.assert_array_equal(back[::-1], got)
+
+
 def test_more_segments_than_one_launch_holds(engine, flags):
     """70 000 overlapping windows in one call: more segments than a grid's y dimension (65 535), so the
     library cuts chunks; fast path (2100 samples) and generic path (700 samples).  Rows must equal
