@@ -47,9 +47,11 @@ struct WhisperTables {
     const v2d* tw400;    // [201] W_400^k
     const double* win;   // [400]
     const float* mel_w;  // sparse taps
-    const int4* mel_rng; // [n_mels] (first bin, count, offset, 0)
+    const int4* mel_rng; // [128] accumulator slots lane, 64 + lane: (first bin, taps, offset, mel or -1)
     int mel_nnz;
     int n_mels;
+    int mel_pair;        // 1: the second slots of lanes 2j, 2j + 1 hold halves of one filter
+
 };
 
 // pass 1: log10(max(mel, 1e-10)) into out[clip][m][t] and the running clip maximum.
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
     for (int i = tid; i < wt.mel_nnz; i += kWWaves * 64) s_melw[i] = wt.mel_w[i];
     __syncthreads();
 
-    const int4 rng0 = (lane < wt.n_mels) ? wt.mel_rng[lane] : int4{0, 0, 0, 0};
-    const int4 rng1 = (lane + 64 < wt.n_mels) ? wt.mel_rng[lane + 64] : int4{0, 0, 0, 0};
+    const int4 rng0 = wt.mel_rng[lane];
+    const int4 rng1 = wt.mel_rng[64 + lane];
     v2d* z = s_z[wave];
     v2d* y = s_y[wave];
     float* p = s_p[wave];
@@ -192,14 +194,15 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
                 if (j < rng0.y) a0 = fmaf(s_melw[rng0.z + j], p[rng0.x + j], a0);
                 if (j < rng1.y) a1 = fmaf(s_melw[rng1.z + j], p[rng1.x + j], a1);
             }
-            if (lane < wt.n_mels) {
+            if (wt.mel_pair) a1 += __shfl_xor(a1, 1);   // lower half of the taps + upper half
+            if (rng0.w >= 0) {
                 const float l = log10f(fmaxf(a0, 1e-10f));
-                s_tile[lane][f] = l;
+                s_tile[rng0.w][f] = l;
                 vmax = fmaxf(vmax, l);
             }
-            if (lane + 64 < wt.n_mels) {
+            if (rng1.w >= 0 && !(wt.mel_pair && (lane & 1))) {
                 const float l = log10f(fmaxf(a1, 1e-10f));
-                s_tile[lane + 64][f] = l;
+                s_tile[rng1.w][f] = l;
                 vmax = fmaxf(vmax, l);
             }
         }

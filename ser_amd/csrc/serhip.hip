@@ -310,7 +310,7 @@ int ensure_whisper_tables(serhip_ctx* ctx, int n_mels) {
     for (int j = 0; j < kWNfft; ++j) win[j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / 400.0);
     const std::vector<float> dense = mel_filterbank(16000, kWNfft, n_mels);
     std::vector<float> mel_w;
-    std::vector<int4> rng(n_mels, int4{0, 0, 0, 0});
+    std::vector<int4> per_mel(n_mels, int4{0, 0, 0, 0});   // first bin, taps, offset into mel_w
     for (int m = 0; m < n_mels; ++m) {
         int first = -1, last = -1;
         for (int k = 0; k < kWBins; ++k)
@@ -319,8 +319,25 @@ int ensure_whisper_tables(serhip_ctx* ctx, int n_mels) {
                 last = k;
             }
         if (first >= 0) {
-            rng[m] = int4{first, last - first + 1, static_cast<int>(mel_w.size()), 0};
+            per_mel[m] = int4{first, last - first + 1, static_cast<int>(mel_w.size()), 0};
             for (int k = first; k <= last; ++k) mel_w.push_back(dense[static_cast<size_t>(m) * kWBins + k]);
+        }
+    }
+    // two accumulator slots per lane (rng[lane], rng[64 + lane]): {first bin, taps, weight offset, mel or -1}.
+    // 128 mels: lane l takes mels l and 64 + l.  80 mels: lane l takes mel l, and the 16 widest filters
+    // (64..79, up to 30 taps) are cut in halves over the second slots of lanes 0..31, whose sums the even
+    // lane of each pair adds up -- the tap loop runs 15 times instead of 30.
+    std::vector<int4> rng(128, int4{0, 0, 0, -1});
+    const bool pair_sum = n_mels == 80;
+    for (int l = 0; l < 64; ++l) {
+        if (l < n_mels) rng[l] = int4{per_mel[l].x, per_mel[l].y, per_mel[l].z, l};
+        if (!pair_sum) {
+            if (64 + l < n_mels) rng[64 + l] = int4{per_mel[64 + l].x, per_mel[64 + l].y, per_mel[64 + l].z, 64 + l};
+        } else if (l < 2 * (n_mels - 64)) {
+            const int m = 64 + (l >> 1);
+            const int c = per_mel[m].y, c0 = (c + 1) / 2;
+            rng[64 + l] = (l & 1) ? int4{per_mel[m].x + c0, c - c0, per_mel[m].z + c0, m}
+                                  : int4{per_mel[m].x, c0, per_mel[m].z, m};
         }
     }
     if (static_cast<int>(mel_w.size()) > kWMelWCap) return fail(SERHIP_E_UNSUPPORTED, "whisper mel taps exceed capacity");
@@ -354,6 +371,7 @@ int ensure_whisper_tables(serhip_ctx* ctx, int n_mels) {
     wt.mel_rng = reinterpret_cast<const int4*>(d + orng);
     wt.mel_nnz = static_cast<int>(mel_w.size());
     wt.n_mels = n_mels;
+    wt.mel_pair = pair_sum ? 1 : 0;
     ctx->whisper_blob[slot] = dev;
     return SERHIP_OK;
 }
