@@ -1,14 +1,18 @@
 // gfx950 kernels of the fast feature path (segments with >= 2048 samples, n_fft = 2048,
 // hop 512) -- the GPU form of ser/_internal/utils/dsp.py:96-136.
 //
-//   k_stft_frames   one wave64 per STFT frame: framing + Hann + 2048-pt real FFT
-//                   (1024-pt complex, radix 16 x 16 x 4, two LDS transposes, the
-//                   radix-4 across quads with DPP), |X| and |X|^2, sparse Slaney mel
-//                   projection, piptrack peak picking.  Writes per frame: magnitudes,
-//                   128 mel powers, the (pitch, mag) peak list.
-//   k_segment_finish one workgroup per segment: log-mel clip/mean -> DCT (MFCC), mel
-//                   mean, tuning estimate (median select + 100-bin histogram), chroma
-//                   projection with the selected filterbank, inf-norm, time mean.
+//   k_stft_frames      persistent, one wave64 per STFT frame: framing + Hann + 2048-pt real FFT
+//                      (1024-pt complex, radix 16 x 16 x 4, two LDS transposes, the radix-4
+//                      across quads with DPP) and |X|.  Writes per frame: the magnitudes in the
+//                      tile order k_project_frames reads, the (pitch, mag) piptrack peak list;
+//                      per segment the largest magnitude.
+//   k_segment_finish<1> one workgroup per segment, before the projection: tuning estimate
+//                      (median of the peak magnitudes by radix select + 100-bin histogram).
+//   k_project_frames   (kernels_project.hpp) chroma and mel projections on the matrix cores.
+//   k_segment_finish<2> one workgroup per segment, after the projection: top_db clip and time
+//                      mean of the log-mel -> DCT (MFCC), mel mean, chroma mean, contrast zeros.
+//   k_segment_finish<0> the same two steps plus an on-device chroma filterbank for the generic
+//                      path (kernels_generic.hpp: segments shorter than 2048 samples).
 #pragma once
 
 #include <hip/hip_runtime.h>

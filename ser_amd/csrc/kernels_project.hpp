@@ -9,8 +9,9 @@
 // so lane (frame i, kk) takes bins 16G+4kk..+3 and uses them as 4 consecutive k-steps), B = the
 // filterbank pre-arranged on the host in the same order.  The mel filterbank is banded, so a
 // 16-filter block only visits the groups its filters touch (~1.3 blocks per group).
-// Epilogue: per-frame inf-norm of the chroma row (a 16-lane DPP reduction) and stores of
-// chroma_norm[t, 16] and mel[t, 128]; the time means are taken by k_segment_finish<2>.
+// Epilogue: per-frame inf-norm of the chroma row (a 16-lane reduction) -> chroma_norm[t, 16]; per
+// retired mel block and 16-frame tile the power sums, dB sums, dB minima and the dB maximum, and the
+// dB rows mel[t, 128] only where top_db might clip them; k_segment_finish<2> takes the time means.
 #pragma once
 
 #include <hip/hip_runtime.h>
