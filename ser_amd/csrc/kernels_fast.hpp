@@ -58,9 +58,13 @@ struct SegDesc {
 };
 
 // work unit of k_stft_frames: frames [t_begin, min(t_begin + unit_frames, n_stft)) of segment seg.  The
-// kernel is persistent: workgroup b walks units b, b + gridDim.x, ... and its waves draw frame after
-// frame of the concatenation of those units from a counter in LDS (no workgroup barrier after set-up;
-// the frames in flight in a workgroup stay neighbours, so the 75 % they share is read from HBM once).
+// kernel is persistent: workgroup b walks the units the host gave it (balanced by frame count: a plain
+// b, b + gridDim.x, ... walk puts all long units on the same workgroups when segment lengths alternate
+// with a period that divides the grid) and its waves draw frame after frame of the concatenation of
+// those units from a counter in LDS (no workgroup barrier after set-up; the frames in flight in a
+// workgroup stay neighbours, so the 75 % they share is read from HBM once).
+// The array the kernel gets starts with gridDim.x + 1 header entries whose `seg` field is the index of
+// workgroup b's first unit in the list that follows (the last one: the number of units).
 struct WorkUnit {
     int seg;              // index into the chunk's descriptor array
     int t_begin;
@@ -193,7 +197,7 @@ __device__ __forceinline__ v2f piptrack_peak(float sm, float s0, float sp, int i
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __restrict__ audio,
                                                              const SegDesc* __restrict__ segs,
-                                                             const WorkUnit* __restrict__ units, int n_units,
+                                                             const WorkUnit* __restrict__ units,
                                                              int unit_frames, PlanTables tb, Scratch sc) {
     __shared__ v2f s_twA[16 * 64];
     __shared__ v2f s_twU[8 * 64];
@@ -231,8 +235,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     // ---- cursor over this workgroup's units (wave-uniform, scalar registers).  `pos` is this wave's
     // position in the concatenation of the workgroup's units (drawn from s_next, so it only grows),
     // `base` the position of the current unit's first frame, `n` its frame count.
-    int u = blockIdx.x;           // the host launches at most n_units workgroups
-    WorkUnit wu = units[u];
+    const WorkUnit* list = units + gridDim.x + 1;
+    int u = units[blockIdx.x].seg;             // every workgroup has at least one unit
+    const int u_end = units[blockIdx.x + 1].seg;
+    WorkUnit wu = list[u];
     SegDesc sd = segs[wu.seg];
     int n = min(unit_frames, sd.n_stft - wu.t_begin);
     int base = 0;
@@ -247,9 +253,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     auto seek = [&]() -> bool {   // move to the unit that holds `pos`; false when the units are used up
         while (pos >= base + n) {
             base += n;
-            u += gridDim.x;
-            if (u >= n_units) return false;
-            wu = units[u];
+            if (++u >= u_end) return false;
+            wu = list[u];
             sd = segs[wu.seg];
             n = min(unit_frames, sd.n_stft - wu.t_begin);
         }

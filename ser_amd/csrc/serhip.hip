@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <queue>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kernels_fast.hpp"
@@ -606,7 +609,8 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
         int64_t first, count;    // range in the descriptor array
         int max_frames;
         bool generic;
-        size_t first_unit = 0, n_units = 0;   // fast chunks: range in the work-unit array
+        size_t first_unit = 0, n_units = 0;   // fast chunks: header + units in the work-unit array, unit count
+        unsigned wgs = 0;                     // workgroups of the persistent k_stft_frames
         int unit_frames = kUnitFramesMax;
     };
     std::vector<SegDesc> descs;
@@ -694,12 +698,47 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
         for (int64_t i = 0; i < c.count; ++i) frames += static_cast<size_t>(descs[static_cast<size_t>(c.first + i)].n_stft);
         const size_t share = (frames + ctx->cu_count - 1) / static_cast<size_t>(ctx->cu_count);
         c.unit_frames = static_cast<int>(std::min<size_t>(kUnitFramesMax, std::max<size_t>(16, (share + 15) / 16 * 16)));
-        c.first_unit = units.size();
+        std::vector<WorkUnit> plain;
         for (int64_t i = 0; i < c.count; ++i) {
             const int n_stft = descs[static_cast<size_t>(c.first + i)].n_stft;
-            for (int t0 = 0; t0 < n_stft; t0 += c.unit_frames) units.push_back(WorkUnit{static_cast<int>(i), t0});
+            for (int t0 = 0; t0 < n_stft; t0 += c.unit_frames) plain.push_back(WorkUnit{static_cast<int>(i), t0});
         }
-        c.n_units = units.size() - c.first_unit;
+        // one workgroup per CU (the kernel's LDS footprint allows no more), never more than units; every
+        // unit goes, in order, to the workgroup with the fewest frames so far
+        c.n_units = plain.size();
+        c.wgs = static_cast<unsigned>(std::min<size_t>(c.n_units, static_cast<size_t>(ctx->cu_count)));
+        std::vector<int> owner(plain.size());
+        std::vector<int> per_wg(c.wgs + 1, 0);
+        auto unit_len = [&](const WorkUnit& w) {
+            return std::min(c.unit_frames, descs[static_cast<size_t>(c.first + w.seg)].n_stft - w.t_begin);
+        };
+        bool uniform = true;
+        for (size_t k = 1; k < plain.size() && uniform; ++k) uniform = unit_len(plain[k]) == unit_len(plain[0]);
+        if (uniform) {   // equal units: least-loaded is round robin
+            for (size_t k = 0; k < plain.size(); ++k) {
+                owner[k] = static_cast<int>(k % c.wgs);
+                per_wg[owner[k] + 1] += 1;
+            }
+        } else {
+            typedef std::pair<long long, int> Load;   // frames so far, workgroup
+            std::priority_queue<Load, std::vector<Load>, std::greater<Load>> q;
+            for (unsigned b = 0; b < c.wgs; ++b) q.push(Load{0, static_cast<int>(b)});
+            for (size_t k = 0; k < plain.size(); ++k) {
+                Load l = q.top();
+                q.pop();
+                l.first += unit_len(plain[k]);
+                owner[k] = l.second;
+                per_wg[l.second + 1] += 1;
+                q.push(l);
+            }
+        }
+        for (unsigned b = 0; b < c.wgs; ++b) per_wg[b + 1] += per_wg[b];
+        c.first_unit = units.size();
+        for (unsigned b = 0; b <= c.wgs; ++b) units.push_back(WorkUnit{per_wg[b], 0});   // header
+        const size_t list0 = units.size();
+        units.resize(list0 + plain.size());
+        std::vector<int> fill(per_wg.begin(), per_wg.end() - 1);
+        for (size_t k = 0; k < plain.size(); ++k) units[list0 + static_cast<size_t>(fill[owner[k]]++)] = plain[k];
     }
 
     // ---- workspace: [descriptors | work units | fast scratch | generic scratch]
@@ -754,11 +793,10 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
         const SegDesc* dd = d_descs + c.first;
         if (!c.generic) {
             HIP_TRY(hipMemsetAsync(sf.seg_cmax, 0, static_cast<size_t>(c.count) * sizeof(unsigned), stream));
-            {   // persistent: one workgroup per CU (its LDS footprint allows no more), never more than units
-                const unsigned wgs = static_cast<unsigned>(std::min<size_t>(c.n_units, static_cast<size_t>(ctx->cu_count)));
+            {
                 LaunchTimer lt(ctx, SERHIP_KERNEL_STFT_FRAMES, stream);
-                hipLaunchKernelGGL(k_stft_frames, dim3(wgs), dim3(kWaves * 64), 0, stream, audio_dev, dd,
-                                   d_units + c.first_unit, static_cast<int>(c.n_units), c.unit_frames, plan->tb, sf);
+                hipLaunchKernelGGL(k_stft_frames, dim3(c.wgs), dim3(kWaves * 64), 0, stream, audio_dev, dd,
+                                   d_units + c.first_unit, c.unit_frames, plan->tb, sf);
             }
             const dim3 segs_grid(static_cast<unsigned>(c.count));
             if (want_chroma || tuning_dev) {   // tuning estimate per segment (zeros when chroma is off)
