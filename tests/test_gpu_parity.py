@@ -223,6 +223,26 @@ def test_more_segments_than_one_launch_holds(engine, flags):
         assert_features_close(got[pick[:3]], want)
 
 
+def test_uneven_units_dealt_by_frame_count(engine, flags):
+    """3 000 segments of four interleaved lengths (period 4 divides every grid size): several work units
+    per persistent workgroup, units of unequal frame counts, so the host deals them least-loaded-first
+    instead of round robin.  Rows must equal the same segments featurised on their own (bit-exact) and
+    the oracle's."""
+    rng = np.random.default_rng(71)
+    x = rng.standard_normal(400000).astype(np.float32)
+    x /= np.abs(x).max()
+    n = 3000
+    lens = np.asarray([48000, 2048, 24000, 70001], dtype=np.int64)[np.arange(n) % 4]
+    offs = (np.arange(n, dtype=np.int64) * 37) % (x.size - 70001)
+    got = engine.features(x, offs, lens, SR, flags).cpu().numpy()
+    assert got.shape == (n, 187) and np.isfinite(got).all()
+    pick = np.asarray([0, 1, 2, 3, 1023, 1024, 1025, 1026, 2996, 2997, 2998, 2999])
+    alone = engine.features(x, offs[pick], lens[pick], SR, flags).cpu().numpy()
+    np.testing.assert_array_equal(got[pick], alone)
+    want, _ = oracle_rows(x, offs[pick[:4]], lens[pick[:4]])
+    assert_features_close(got[pick[:4]], want)
+
+
 def test_silence_and_constant(engine, flags):
     z = np.zeros(9000, np.float32)
     got, tun = gpu_rows(engine, flags, z, [0, 100], [9000, 1000])
