@@ -17,7 +17,11 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *     Work is enqueued asynchronously; outputs are valid once the stream has
  *     been synchronised.  Host descriptor arrays may be reused as soon as the
- *     call returns.
+ *     call returns.  Calls on one context share its device workspace: on one
+ *     stream they are ordered by the stream; a call on another stream than the
+ *     previous call's first waits on the device (hipStreamWaitEvent) for that
+ *     call's kernels, so streams may be switched between calls without a
+ *     host synchronisation.
  *   - a serhip_ctx is bound to one device and is not thread-safe; distinct
  *     contexts are independent.  Handles are opaque.
  */

@@ -144,6 +144,11 @@ struct serhip_ctx {
     void* staging = nullptr;     // pinned host staging for descriptors
     size_t staging_bytes = 0;
     hipEvent_t staging_done = nullptr;
+    // the workspace is shared by every call on the context: the last user's stream and an event behind its
+    // last launch (WorkspaceUse)
+    hipEvent_t ws_done = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_marked = false;
     size_t chunk_frames = 0;     // frames of scratch per chunk (0 = default)
     int cu_count = 256;          // compute units: grid size of the persistent k_stft_frames
     // serhip_fast_features skips the descriptor upload when the workspace still holds the same plan
@@ -201,6 +206,23 @@ int ensure_workspace(serhip_ctx* ctx, size_t bytes) {
     }
     return SERHIP_OK;
 }
+
+// Calls on one stream are ordered by the stream.  A call on another stream than the previous user of the
+// workspace first waits, on the device, for that user's last launch; every user leaves its mark when it
+// has enqueued its work (also on the error paths: whatever it did enqueue is covered).
+struct WorkspaceUse {
+    serhip_ctx* ctx;
+    hipStream_t stream;
+    WorkspaceUse(serhip_ctx* c, hipStream_t s) : ctx(c), stream(s) {
+        if (c->ws_marked && c->ws_stream != s) (void)hipStreamWaitEvent(s, c->ws_done, 0);
+    }
+    ~WorkspaceUse() {
+        ctx->ws_marked = hipEventRecord(ctx->ws_done, stream) == hipSuccess;
+        ctx->ws_stream = stream;
+    }
+    WorkspaceUse(const WorkspaceUse&) = delete;
+    WorkspaceUse& operator=(const WorkspaceUse&) = delete;
+};
 
 int ensure_staging(serhip_ctx* ctx, size_t bytes) {
     if (ctx->staging_done) HIP_TRY(hipEventSynchronize(ctx->staging_done));
@@ -386,6 +408,7 @@ int whisper_logmel_launch(serhip_ctx* ctx, const float* audio_dev, int32_t n_cli
     if (n_clips > 65535) return fail(SERHIP_E_UNSUPPORTED, "serhip_whisper_logmel: more than 65535 clips per call");
     rc = ensure_workspace(ctx, align_up(static_cast<size_t>(n_clips) * sizeof(unsigned), 256));
     if (rc != SERHIP_OK) return rc;
+    WorkspaceUse use(ctx, stream);
     unsigned* clip_max = reinterpret_cast<unsigned*>(ctx->ws);
     HIP_TRY(hipMemsetAsync(clip_max, 0, static_cast<size_t>(n_clips) * sizeof(unsigned), stream));
     const int n_frames = static_cast<int>(n_samples / kWHop);
@@ -420,7 +443,9 @@ int serhip_create(int device_id, serhip_ctx** out) {
     HIP_TRY(hipSetDevice(device_id));
     serhip_ctx* ctx = new serhip_ctx();
     ctx->device = device_id;
-    if (hipEventCreateWithFlags(&ctx->staging_done, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&ctx->staging_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws_done, hipEventDisableTiming) != hipSuccess) {
+        if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
         delete ctx;
         return fail(SERHIP_E_HIP, "serhip_create: hipEventCreate failed");
     }
@@ -448,6 +473,7 @@ void serhip_destroy(serhip_ctx* ctx) {
         if (b) (void)hipFree(b);
     if (ctx->staging) (void)hipHostFree(ctx->staging);
     if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
+    if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
     for (const serhip_ctx::Timed& t : ctx->timed) {
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
@@ -751,6 +777,7 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
     const ScratchLayout lg = scratch_layout(std::max(gen_frames_max, gen_mel_max), kGenericPeakCap, 0);
     int rc = ensure_workspace(ctx, desc_bytes + lf.total + lg.total);
     if (rc != SERHIP_OK) return rc;
+    WorkspaceUse use(ctx, stream);
     // descriptors and units travel in one copy: the staging buffer mirrors the head of the workspace
     const size_t head_bytes = seg_bytes + units.size() * sizeof(WorkUnit);
     const size_t desc_raw = descs.size() * sizeof(SegDesc), unit_raw = units.size() * sizeof(WorkUnit);
@@ -849,6 +876,7 @@ int serhip_pool_windows(serhip_ctx* ctx, const float* emb_dev, int32_t n_frames,
     const size_t bytes = static_cast<size_t>(n_win) * sizeof(int32_t);
     int rc = ensure_workspace(ctx, 2 * align_up(bytes, 256));
     if (rc != SERHIP_OK) return rc;
+    WorkspaceUse use(ctx, stream);
     rc = ensure_staging(ctx, 2 * bytes);
     if (rc != SERHIP_OK) return rc;
     std::memcpy(ctx->staging, win_lo, bytes);
@@ -908,6 +936,7 @@ int serhip_prepare_audio(serhip_ctx* ctx, const void* raw_dev, int64_t raw_bytes
     const size_t peak_bytes = align_up(clips.size() * sizeof(unsigned), 256);
     int rc = ensure_workspace(ctx, desc_bytes + peak_bytes);
     if (rc != SERHIP_OK) return rc;
+    WorkspaceUse use(ctx, stream);
     rc = ensure_staging(ctx, clips.size() * sizeof(PrepClip));
     if (rc != SERHIP_OK) return rc;
     std::memcpy(ctx->staging, clips.data(), clips.size() * sizeof(PrepClip));
@@ -969,6 +998,7 @@ int serhip_mlp_predict(serhip_ctx* ctx, const void* x_dev, int x_is_f64, int64_t
     const size_t buf_bytes = align_up(static_cast<size_t>(n_rows) * max_width * sizeof(double), 256);
     int rc = ensure_workspace(ctx, 2 * buf_bytes);
     if (rc != SERHIP_OK) return rc;
+    WorkspaceUse use(ctx, stream);
     double* ping = reinterpret_cast<double*>(ctx->ws);
     double* pong = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + buf_bytes);
     const long long total = static_cast<long long>(n_rows) * n_features;

@@ -395,6 +395,59 @@ def test_repeated_plan_skips_descriptor_upload_safely(engine, flags):
     np.testing.assert_array_equal(again, first)
 
 
+def test_calls_on_alternating_streams_share_the_workspace_safely(engine, flags):
+    """Back-to-back calls on two different HIP streams, no host synchronisation in between: every call
+    uses the context's one workspace, so the library orders them on the device (include/serhip.h,
+    conventions).  Each result must equal the same call made alone."""
+    import torch
+
+    from ser_amd.synth import harmonic_clips
+
+    n = 600                                    # ~0.2 ms of kernels per call: calls do overlap if unordered
+    audios = [torch.from_numpy(harmonic_clips(600 + k, n, 48000).reshape(-1)).to(engine.device) for k in range(2)]
+    offs, lens = [i * 48000 for i in range(n)], [48000] * n
+    short_lens = [30000] * n                   # another plan: other scratch offsets in the same workspace
+    alone = [engine.features(audios[0], offs, lens, SR, flags).cpu().numpy(),
+             engine.features(audios[1], offs, short_lens, SR, flags).cpu().numpy()]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=engine.device) for _ in range(2)]
+    outs = []
+    for rep in range(6):
+        k = rep % 2
+        with torch.cuda.stream(streams[k]):
+            outs.append(engine.features(audios[k], offs, lens if k == 0 else short_lens, SR, flags))
+    torch.cuda.synchronize()
+    for rep, out in enumerate(outs):
+        np.testing.assert_array_equal(out.cpu().numpy(), alone[rep % 2])
+
+
+def test_worker_thread_and_spawned_process(engine, flags):
+    """The reference runs inference on a ThreadPoolExecutor(max_workers=1) thread when a timeout is set
+    (runtime/worker_lifecycle.py:98-118) and inside spawned workers: the engine must work
+    from a non-main thread and in a fresh spawned process (lazy per-process context)."""
+    import multiprocessing as mp
+    from concurrent.futures import ThreadPoolExecutor
+
+    from ser_amd import HandcraftedBackend
+    from ser_amd.synth import sample_wav_like
+
+    audio = sample_wav_like(seed=5, n_samples=50000)
+    backend = HandcraftedBackend(feature_flags=flags)
+    here = backend.extract_vector(audio, SR)
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        there = pool.submit(backend.extract_vector, audio, SR).result(timeout=100)
+    np.testing.assert_array_equal(there, here)
+    with mp.get_context("spawn").Pool(1) as workers:
+        spawned = workers.apply_async(_extract_in_worker, (audio, SR)).get(timeout=110)
+    np.testing.assert_array_equal(spawned, here)
+
+
+def _extract_in_worker(audio, sr):
+    from ser_amd import FeatureFlags, HandcraftedBackend
+
+    return HandcraftedBackend(feature_flags=FeatureFlags(tonnetz=False)).extract_vector(audio, sr)
+
+
 def test_pooling_kernels_bit_exact(engine):
     """mean_std_pool / HandcraftedBackend.pool on the GPU equal numpy bit for bit."""
     from oracle import ser_fast_path as ofp
