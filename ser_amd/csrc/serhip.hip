@@ -144,8 +144,8 @@ struct serhip_ctx {
     void* staging = nullptr;     // pinned host staging for descriptors
     size_t staging_bytes = 0;
     hipEvent_t staging_done = nullptr;
-    // the workspace is shared by every call on the context: the last user's stream and an event behind its
-    // last launch (WorkspaceUse)
+    // the workspace is shared by every call on the context: the last user's stream, and the event a call on
+    // another stream records there and waits for (WorkspaceUse)
     hipEvent_t ws_done = nullptr;
     hipStream_t ws_stream = nullptr;
     bool ws_marked = false;
@@ -208,16 +208,23 @@ int ensure_workspace(serhip_ctx* ctx, size_t bytes) {
 }
 
 // Calls on one stream are ordered by the stream.  A call on another stream than the previous user of the
-// workspace first waits, on the device, for that user's last launch; every user leaves its mark when it
-// has enqueued its work (also on the error paths: whatever it did enqueue is covered).
+// workspace first waits, on the device, for everything enqueued so far on that user's stream.  The event
+// is recorded only then, so calls that stay on one stream pay nothing.  If the old stream cannot take the
+// event any more (the caller destroyed it), the device is drained instead.
 struct WorkspaceUse {
     serhip_ctx* ctx;
     hipStream_t stream;
     WorkspaceUse(serhip_ctx* c, hipStream_t s) : ctx(c), stream(s) {
-        if (c->ws_marked && c->ws_stream != s) (void)hipStreamWaitEvent(s, c->ws_done, 0);
+        if (c->ws_marked && c->ws_stream != s) {
+            if (hipEventRecord(c->ws_done, c->ws_stream) != hipSuccess ||
+                hipStreamWaitEvent(s, c->ws_done, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+            }
+        }
     }
     ~WorkspaceUse() {
-        ctx->ws_marked = hipEventRecord(ctx->ws_done, stream) == hipSuccess;
+        ctx->ws_marked = true;
         ctx->ws_stream = stream;
     }
     WorkspaceUse(const WorkspaceUse&) = delete;
