@@ -502,10 +502,10 @@ struct FinishShared {
     unsigned hist[kMode == 2 ? 1 : 2048];
     float red[64];
     int ired[8];
-    double lmean[kMels];
-    double melsum[2][kMels];
-    double lsum[2][kMels];
-    float chroma_acc[4][16];
+    double lmean[kMode == 1 ? 1 : kMels];          // the tuning-only kernel keeps none of the mel / chroma sums
+    double melsum[2][kMode == 1 ? 1 : kMels];      // (25 KB instead of 30 KB; its time did not change: 0.20 ms)
+    double lsum[2][kMode == 1 ? 1 : kMels];
+    float chroma_acc[kMode == 1 ? 1 : 4][16];
     unsigned sel_prefix, sel_k;
     unsigned sel_cnt, sel_cum;   // pass 0 of select_kth: keys in the selected bucket / in the buckets below it
     double edges[kMode == 2 ? 1 : kTunings];   // histogram edges (a copy: two dependent reads per peak)
