@@ -944,15 +944,14 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
             if (pm.y >= thr && pm.x > 0.0f) atomicAdd(&sh.hist[tuning_bin(tuning_residual(pm.x), sh.edges)], 1u);
         });
         __syncthreads();
-        if (tid == 0) {
-            unsigned best = 0;
-            int arg = 0;
-            for (int b = 0; b < 100; ++b)
-                if (sh.hist[b] > best) {
-                    best = sh.hist[b];
-                    arg = b;
-                }
-            sh.tuning_idx = arg;
+        if (wave == 0) {
+            // np.argmax: the first of the largest counts.  One wave, two bins per lane; the key orders by
+            // count, then by smaller bin number (counts are far below 2^24)
+            unsigned key = 0;
+            if (lane < 100) key = (sh.hist[lane] << 8) | static_cast<unsigned>(255 - lane);
+            if (lane + 64 < 100) key = max(key, (sh.hist[lane + 64] << 8) | static_cast<unsigned>(255 - (lane + 64)));
+            key = wave_max_bits(key);
+            if (lane == 0) sh.tuning_idx = 255 - static_cast<int>(key & 255u);
         }
         __syncthreads();
         tuning_idx = sh.tuning_idx;
