@@ -37,6 +37,9 @@ FEATURE_DIM = 187
 CLIPS_PER_GPU = 12500
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_CLIP = 4 * CLIP_SAMPLES + 4 * FEATURE_DIM   # 192 748 B
+FRAMES_PER_CLIP = 1 + CLIP_SAMPLES // 512                  # 94 STFT frames (hop 512, centred)
+FFT_FLOP_PER_FRAME = 2.5 * 2048 * 11                       # 56 320: 2.5 N log2 N for a real 2048-point FFT
+VALU_F32_PEAK_TFLOPS = 157.3                               # packed-f32 vector peak, MI355X_MICROARCH.md
 
 
 def _cpu_worker(seed: int) -> int:
@@ -230,6 +233,13 @@ def main() -> None:
                 "finish_kernels_ms_per_step": k2_ms / max(1, args.steps),
                 "project_kernel_ms_per_step": k3_ms / max(1, args.steps),
                 "whole_path_frac": (value / world) * (ALGO_BYTES_PER_CLIP / CLIP_SECONDS) / 1e9 / HBM_PEAK_GBS,
+                # what actually binds this kernel (SURVEY.md 8d asks to say so): vector-ALU instruction issue.
+                # Useful butterfly arithmetic of a 2048-point real FFT, 2.5 N log2 N = 56 320 flop per frame,
+                # against the packed-f32 vector peak of the guide.
+                "binding": "valu",
+                "valu_achieved_tflops": n_local * FRAMES_PER_CLIP * FFT_FLOP_PER_FRAME / k1_s_per_step / 1e12
+                                        if k1_s_per_step > 0 else 0.0,
+                "valu_peak_tflops": VALU_F32_PEAK_TFLOPS,
             },
             "cpu_baseline": cpu,
         }
