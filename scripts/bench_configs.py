@@ -72,13 +72,16 @@ def main():
                       "hbm_roofline_frac": (3600.0 / dt) * (4 * SR + 4 * 187) / HBM}
     backend = HandcraftedBackend(feature_flags=FLAGS)
     host_hour = hour.cpu().numpy()
-    t0 = time.perf_counter()
-    enc = backend.encode_sequence(host_hour, SR)
-    wins = temporal_pooling_windows(enc, window_size_seconds=10.0, window_stride_seconds=5.0)
-    pooled = mean_std_pool(enc, wins)
+    times = []
+    for _ in range(3):   # the first pass pays one-time costs (pooling workspace, page faults of the host buffer)
+        t0 = time.perf_counter()
+        enc = backend.encode_sequence(host_hour, SR)
+        wins = temporal_pooling_windows(enc, window_size_seconds=10.0, window_stride_seconds=5.0)
+        pooled = mean_std_pool(enc, wins)
+        times.append((time.perf_counter() - t0) * 1e3)
     res["config4_host_api"] = {"what": "same through HandcraftedBackend.encode_sequence (230 MB H2D) + "
-                                       "temporal_pooling_windows + mean_std_pool", "ms": (time.perf_counter() - t0) * 1e3,
-                               "pooled_shape": list(pooled.shape)}
+                                       "temporal_pooling_windows + mean_std_pool", "ms": min(times[1:]),
+                               "first_call_ms": times[0], "pooled_shape": list(pooled.shape)}
     del hour
     # ---- config 5: whisper log-mel, 64 clips x 30 s
     b = 64

@@ -26,7 +26,6 @@ from .types import (
     FeatureMatrix,
     FeatureVector,
     PoolingWindow,
-    overlap_frame_range,
 )
 
 
@@ -96,9 +95,9 @@ class HandcraftedBackend:
         dim = int(encoded.embeddings.shape[1])
         if not windows:
             return np.empty((0, dim), dtype=np.float64)
-        ranges = [overlap_frame_range(encoded, w) for w in windows]
-        lo = [r[0] for r in ranges]
-        hi = [r[1] for r in ranges]
+        from .pool import window_frame_ranges
+
+        lo, hi = window_frame_ranges(encoded, windows)
         out = get_engine().pool_windows(np.asarray(encoded.embeddings, dtype=np.float32), lo, hi, mode=1)
         return out.cpu().numpy()
 

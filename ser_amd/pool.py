@@ -56,11 +56,22 @@ def temporal_pooling_windows(
 
 
 def window_frame_ranges(encoded: EncodedSequence, windows: Sequence[PoolingWindow]):
-    """``(lo, hi)`` int32 arrays of the frame range each window overlaps (validates like the reference)."""
-    ranges = [overlap_frame_range(encoded, w) for w in windows]
-    lo = np.asarray([r[0] for r in ranges], dtype=np.int32)
-    hi = np.asarray([r[1] for r in ranges], dtype=np.int32)
-    return lo, hi
+    """``(lo, hi)`` int32 arrays of the frame range each window overlaps.
+
+    All windows in two ``searchsorted`` calls; validates like the reference's per-window walk
+    (``overlap_frame_mask``, repr/backend.py:94-110): the first offending window, in order, raises its
+    error through :func:`overlap_frame_range`."""
+    if len(windows) == 0:
+        return np.empty(0, dtype=np.int32), np.empty(0, dtype=np.int32)
+    t0, t1 = encoded.frame_start_seconds, encoded.frame_end_seconds
+    ws = np.asarray([w.start_seconds for w in windows], dtype=np.float64)
+    we = np.asarray([w.end_seconds for w in windows], dtype=np.float64)
+    lo = np.searchsorted(t1, ws, side="right")   # first frame with end > window start
+    hi = np.searchsorted(t0, we, side="left")    # first frame with start >= window end
+    bad = (ws < float(t0[0])) | (we > float(t1[-1])) | (hi <= lo)
+    if bad.any():
+        overlap_frame_range(encoded, windows[int(np.argmax(bad))])   # raises the reference's message
+    return lo.astype(np.int32), hi.astype(np.int32)
 
 
 def mean_std_pool(encoded: EncodedSequence, windows: Sequence[PoolingWindow]) -> NDArray[np.float64]:

@@ -111,6 +111,32 @@ def test_overlap_mask_and_ranges():
             np.testing.assert_array_equal(overlap_frame_mask(enc2, PoolingWindow(a, b)), ref)
 
 
+def test_window_frame_ranges_vectorised_equals_per_window_walk():
+    """All windows at once (two searchsorted calls) against the reference-shaped walk, window by window;
+    a bad window raises the error of the FIRST bad one, as the reference's loop does."""
+    from ser_amd.types import overlap_frame_range
+
+    rng = np.random.default_rng(1)
+    starts = np.sort(rng.random(60) * 20)
+    ends = np.maximum.accumulate(starts + 0.3 + rng.random(60))
+    enc = seq(np.zeros((60, 1)), starts, ends)
+    wins = []
+    for _ in range(200):
+        a = rng.uniform(starts[0], ends[-1] - 0.01)
+        wins.append(PoolingWindow(a, rng.uniform(a + 0.001, ends[-1])))
+    lo, hi = window_frame_ranges(enc, wins)
+    assert lo.dtype == hi.dtype == np.int32
+    assert [(int(a), int(b)) for a, b in zip(lo, hi)] == [overlap_frame_range(enc, w) for w in wins]
+    lo0, hi0 = window_frame_ranges(enc, [])
+    assert lo0.size == hi0.size == 0
+    gap = seq([[1], [2]], [0.0, 2.0], [1.0, 3.0])
+    inside, hole, outside = PoolingWindow(0.1, 0.9), PoolingWindow(1.2, 1.8), PoolingWindow(0.0, 6.0)
+    with pytest.raises(ValueError, match="does not overlap any encoded frames"):
+        window_frame_ranges(gap, [inside, hole, outside])
+    with pytest.raises(ValueError, match="outside encoded sequence range"):
+        window_frame_ranges(gap, [inside, outside, hole])
+
+
 def test_temporal_pooling_windows_known_answers():
     # tests/suites/unit/repr/test_pooling.py:78-138
     enc = seq(np.zeros((4, 2)), [0, 1, 2, 3], [1, 2, 3, 4])
