@@ -7,7 +7,10 @@ this process touches the GPU) and reports what the tests can only sample: how ma
 agree exactly, the worst normalised error per feature block (<= 1 passes the BASELINE.md gate), and
 what the disagreeing clips look like.  The oracle is used here as the checker only.
 
-    python scripts/parity_at_scale.py --clips 2000 [--kind harmonic|noisy] [--out report.json]
+    python scripts/parity_at_scale.py --clips 2000 [--kind harmonic|noisy|windows] [--out report.json]
+
+``--kind windows`` is config 4's shape: ONE recording of ``--clips`` seconds, featurised as overlapping
+3 s windows at a 1 s stride (the last two windows are shorter), every window against the oracle.
 """
 
 from __future__ import annotations
@@ -39,18 +42,34 @@ def make_clip(seed: int, kind: str):
     return clip
 
 
+def make_recording(seconds: int, seed: int):
+    import numpy as np
+
+    from ser_amd.synth import harmonic_clip, peak_normalise
+
+    rng = np.random.default_rng(seed)
+    return peak_normalise(np.concatenate([harmonic_clip(rng, SR, SR) for _ in range(seconds)]))
+
+
+_RECORDING = None   # set before the pool forks: the workers inherit it
+
+
 def _oracle_row(args):
     seed, kind = args
     from oracle import ser_fast_path as ofp
 
-    v, dbg = ofp.extract_feature_from_signal(make_clip(seed, kind), SR, flags=ofp.Flags(), return_debug=True)
+    if kind == "windows":
+        clip = _RECORDING[seed * SR : seed * SR + N]
+    else:
+        clip = make_clip(seed, kind)
+    v, dbg = ofp.extract_feature_from_signal(clip, SR, flags=ofp.Flags(), return_debug=True)
     return v, dbg.get("tuning", 0.0)
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=2000)
-    ap.add_argument("--kind", choices=("harmonic", "noisy"), default="harmonic")
+    ap.add_argument("--kind", choices=("harmonic", "noisy", "windows"), default="harmonic")
     ap.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1))
     ap.add_argument("--seed0", type=int, default=500000)
     ap.add_argument("--out", type=str, default="")
@@ -61,7 +80,12 @@ def main() -> None:
     import numpy as np
 
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    seeds = list(range(args.seed0, args.seed0 + args.clips))
+    global _RECORDING
+    if args.kind == "windows":
+        _RECORDING = make_recording(args.clips, args.seed0)
+        seeds = list(range(args.clips))                      # window w starts at second w
+    else:
+        seeds = list(range(args.seed0, args.seed0 + args.clips))
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(args.workers) as pool:
         rows = pool.map(_oracle_row, [(s, args.kind) for s in seeds], chunksize=max(1, args.clips // (8 * args.workers)))
@@ -74,10 +98,15 @@ def main() -> None:
     from ser_amd import FeatureFlags
     from ser_amd.engine import get_engine
 
-    audio = np.concatenate([make_clip(s, args.kind) for s in seeds])
     eng = get_engine()
-    out, tun = eng.features(audio, [i * N for i in range(args.clips)], [N] * args.clips, SR,
-                            FeatureFlags(tonnetz=False), return_tuning=True)
+    if args.kind == "windows":
+        audio = _RECORDING
+        offs = [w * SR for w in range(args.clips)]
+        lens = [min(N, audio.size - o) for o in offs]
+    else:
+        audio = np.concatenate([make_clip(s, args.kind) for s in seeds])
+        offs, lens = [i * N for i in range(args.clips)], [N] * args.clips
+    out, tun = eng.features(audio, offs, lens, SR, FeatureFlags(tonnetz=False), return_tuning=True)
     got = out.cpu().numpy().astype(np.float64)
     got_tun = tun.cpu().numpy().astype(np.float64)
 
