@@ -600,6 +600,28 @@ def test_config5_whisper_logmel(engine):
     np.testing.assert_allclose(got[0], hf[0][:, :500], atol=1e-5)
 
 
+def test_config5_full_length_clips_vs_hf_extractor(engine):
+    """Config 5 at its real clip length: 30 s clips -> [B, 80, 3000], every value against HF's
+    WhisperFeatureExtractor (numpy path; the pinned stand-in for whisper.log_mel_spectrogram), atol 1e-5,
+    and against the oracle for the 128-bin variant."""
+    from transformers.models.whisper.feature_extraction_whisper import WhisperFeatureExtractor
+
+    from oracle.whisper_logmel import log_mel_spectrogram as oracle_logmel
+    from ser_amd import log_mel_spectrogram
+    from ser_amd.synth import harmonic_clips
+
+    clips = harmonic_clips(99, 6, 16000 * 30)
+    clips[4, 200000:] = 0.0                      # long silence: the per-clip max - 8 clamp takes over
+    clips[5] *= np.float32(1e-3)                 # quiet clip
+    got = log_mel_spectrogram(clips, 80)
+    assert got.shape == (6, 80, 3000) and got.dtype == np.float32
+    hf = WhisperFeatureExtractor()._np_extract_fbank_features(clips.astype(np.float64), "cpu")
+    np.testing.assert_allclose(got, np.asarray(hf)[:, :, :3000], atol=1e-5)
+    wide = log_mel_spectrogram(clips[:2], 128)
+    for i in range(2):
+        np.testing.assert_allclose(wide[i], oracle_logmel(clips[i], 128), atol=1e-5)
+
+
 def test_against_committed_golden_vectors(engine, flags):
     """GPU path vs tests/golden/fast_path_golden.npz (no oracle run needed on the GPU box)."""
     from pathlib import Path
