@@ -53,6 +53,21 @@ def _cpu_worker(seed: int) -> int:
     return 1
 
 
+_BLAS_LIMIT = None
+
+
+def _one_thread_per_process() -> None:
+    """One BLAS/OpenMP thread in this process (kept for its lifetime): the box exports OMP_NUM_THREADS=16,
+    and eight workers with sixteen threads each on sixteen cores ran at a third of the rate measured here."""
+    global _BLAS_LIMIT
+    import numpy  # noqa: F401  (the libraries must be loaded before they can be limited)
+    import scipy.fft  # noqa: F401
+    import scipy.linalg  # noqa: F401
+    from threadpoolctl import threadpool_limits
+
+    _BLAS_LIMIT = threadpool_limits(limits=1)
+
+
 def cpu_baseline(n_clips: int, workers: int) -> dict:
     """Time the oracle (reference-faithful call structure) on `workers` host processes.
 
@@ -60,18 +75,27 @@ def cpu_baseline(n_clips: int, workers: int) -> dict:
     """
     import multiprocessing as mp
 
-    os.environ.setdefault("OMP_NUM_THREADS", "1")
     ctx = mp.get_context("fork")
-    with ctx.Pool(workers) as pool:
+    with ctx.Pool(workers, initializer=_one_thread_per_process) as pool:
         pool.map(_cpu_worker, range(workers))            # warm-up: imports, filterbank code paths
         t0 = time.perf_counter()
         chunk = max(1, n_clips // (4 * workers))         # reference chunking, data_loader.py:374-379
         done = sum(pool.imap_unordered(_cpu_worker, range(1000, 1000 + n_clips), chunksize=chunk))
         dt = time.perf_counter() - t0
+    # the same code on ONE core (SURVEY.md 8d asks for both): a twentieth of the sample, this process
+    n_single = max(8, n_clips // 20)
+    _one_thread_per_process()
+    _cpu_worker(999)
+    t1 = time.perf_counter()
+    for seed in range(5000, 5000 + n_single):
+        _cpu_worker(seed)
+    dt_single = time.perf_counter() - t1
     return {
         "value": done * CLIP_SECONDS / dt,
         "unit": "audio-seconds/s",
         "cores": workers,
+        "single_core_value": n_single * CLIP_SECONDS / dt_single,
+        "threads_per_process": 1,
         "kind": "port",
         "sample": f"{done} of the config-3 clips (3 s @16 kHz), numpy/scipy restatement of the reference "
                   f"(oracle/), multiprocessing.Pool({workers}) like data_loader.py:374-379, {dt:.1f} s wall",
@@ -84,7 +108,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips-per-gpu", type=int, default=CLIPS_PER_GPU)
-    ap.add_argument("--cpu-clips", type=int, default=800, help="clips in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-clips", type=int, default=4000, help="clips in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=8)
     # rehearsal of the N > 1 code path on a one-GPU box: every rank on the same device, gloo for the
     # collectives (features are copied to the host for the gather).  Not a measurement.
