@@ -210,6 +210,24 @@ def prepare_audio_buffer(raw: np.ndarray) -> np.ndarray:
     return prepared / max_abs
 
 
+def librosa_load_mono(frames: np.ndarray) -> np.ndarray:
+    """The mix-down inside ``librosa.load(path, sr=None)`` as ``read_audio_file`` calls it
+    (utils/audio_utils.py:104-109; librosa 0.11 ``core/audio.py``: ``y = sf.read(dtype=float32).T`` then
+    ``to_mono(y) = np.mean(y, axis=tuple(range(y.ndim - 1)))``).  ``frames`` is what soundfile returns:
+    ``[n]`` or ``[n, channels]`` float32.  No scrub happens here: a NaN in one channel makes the frame NaN."""
+    y = np.asarray(frames, dtype=np.float32).T
+    if y.ndim > 1:
+        with np.errstate(invalid="ignore", over="ignore"):
+            y = np.mean(y, axis=tuple(range(y.ndim - 1)))
+    return np.asarray(y, dtype=np.float32)
+
+
+def read_audio_prepared(frames: np.ndarray) -> np.ndarray:
+    """Primary path of ``read_audio_file`` after decoding (utils/audio_utils.py:104-113):
+    ``librosa.load`` (mono mix-down) -> ``_prepare_audio_buffer`` (scrub, peak-normalise)."""
+    return prepare_audio_buffer(librosa_load_mono(frames))
+
+
 def synthetic_ravdess_clip(actor_id: int, emotion_code: int, *, sample_rate: int = 16000,
                            duration_seconds: float = 1.5, amplitude: float = 0.15) -> np.ndarray:
     """PCM16 sine clip of ``scripts/build_synthetic_ravdess_dataset.py:76-141`` as decoded audio.

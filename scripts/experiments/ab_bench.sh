@@ -1,7 +1,7 @@
 #!/bin/bash
-# bench.py with each experimental build of the library (scratch/ab/*.so) and with the tree's own
+# bench.py with each experimental build of the library (scripts/experiments/ab/*.so) and with the tree's own
 set -e
-for lib in ser_amd/libserhip.so scratch/ab/*.so; do
+for lib in ser_amd/libserhip.so scripts/experiments/ab/*.so; do
   echo "$lib"
   SERHIP_LIBRARY=$lib timeout -k 10 120 python bench.py --cpu-clips 0 --steps 10 | python -c "
 import json,sys

@@ -17,6 +17,8 @@ from .types import (  # noqa: F401
     FeatureFrame,
     PoolingWindow,
     VectorFeatureBackend,
+    coerce_feature_flags,
+    default_feature_flags,
     overlap_frame_mask,
     overlap_frame_range,
 )
@@ -43,11 +45,10 @@ _LAZY = {
     "write_prepared_feature_payload": ("prepared_cache", "write_prepared_feature_payload"),
     "read_prepared_feature_payload": ("prepared_cache", "read_prepared_feature_payload"),
     "GpuEmotionClassifier": ("classifier", "GpuEmotionClassifier"),
-    "predict_emotions_detailed_with_model": ("fast_inference", "predict_emotions_detailed_with_model"),
-    "segment_predictions": ("fast_inference", "segment_predictions"),
-    "InferenceResult": ("fast_inference", "InferenceResult"),
-    "FramePrediction": ("fast_inference", "FramePrediction"),
-    "SegmentPrediction": ("fast_inference", "SegmentPrediction"),
+    "merge_label_runs": ("label_runs", "merge_label_runs"),
+    "classify_sequence": ("label_runs", "classify_sequence"),
+    "LabelRuns": ("label_runs", "LabelRuns"),
+    "default_split_utterances": ("data_loader", "default_split_utterances"),
 }
 
 
@@ -62,5 +63,5 @@ def __getattr__(name: str):
 
 __all__ = [
     "FAST_PATH_FLAGS", "AudioReadConfig", "EncodedSequence", "FeatureBackend", "FeatureFlags", "FeatureFrame",
-    "PoolingWindow", "VectorFeatureBackend", "overlap_frame_mask", "overlap_frame_range", *_LAZY,
+    "PoolingWindow", "VectorFeatureBackend", "coerce_feature_flags", "default_feature_flags", "overlap_frame_mask", "overlap_frame_range", *_LAZY,
 ]

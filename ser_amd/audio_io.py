@@ -36,16 +36,22 @@ class AudioDecodeError(OSError):
 
 
 def prepare_audio_buffer(raw_audio) -> NDArray[np.float32]:
-    """float32 cast, non-finite -> 0, mono (mean over channels axis 1), peak-normalise."""
+    """float32 cast, mono (float32 mean over the channel axis), non-finite -> 0, peak-normalise.
+
+    Order as on the reference's primary path: ``librosa.load(sr=None)`` mixes down (``mono=True``)
+    BEFORE ``_prepare_audio_buffer`` applies ``nan_to_num`` (audio_utils.py:104-110), so a NaN or inf
+    in one channel zeroes that frame instead of being dropped from the mean.  (The soundfile fallback
+    scrubs first; it only runs when librosa fails.)  The device kernel ``k_prepare_convert`` does the same."""
     buf = np.array(raw_audio, dtype=np.float32, copy=True)
-    np.nan_to_num(buf, copy=False, nan=0.0, posinf=0.0, neginf=0.0)
     if buf.ndim == 2:
         if buf.shape[1] == 0:
             buf = np.empty(0, dtype=np.float32)
         else:
-            buf = np.asarray(np.mean(buf, axis=1, dtype=np.float32), dtype=np.float32)
+            with np.errstate(invalid="ignore", over="ignore"):
+                buf = np.asarray(np.mean(buf, axis=1, dtype=np.float32), dtype=np.float32)
     elif buf.ndim != 1:
         raise OSError(f"Unsupported audio shape: {buf.shape}")
+    np.nan_to_num(buf, copy=False, nan=0.0, posinf=0.0, neginf=0.0)
     if buf.size == 0:
         raise OSError("Audio file contains no samples.")
     peak = float(np.max(np.abs(buf)))
@@ -206,6 +212,11 @@ def read_audio_file(
                 duration_seconds=float(duration_seconds) if duration_seconds is not None else None,
             )
             return prepare_audio_buffer(samples), int(rate)
+        except AudioDecodeError as err:
+            # the parser's verdict on these bytes is deterministic: retrying (and sleeping) cannot change
+            # it.  Only WAVE is decoded here (module docstring); name the container / encoding at once.
+            logger.error("Failed to read audio file %s: %s", file_path, err)
+            raise AudioDecodeError(f"Error reading {file_path}: {err}") from err
         except Exception as err:
             last_error = err
             detail = str(err).strip() or type(err).__name__

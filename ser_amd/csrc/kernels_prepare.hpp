@@ -2,9 +2,13 @@
 // (_prepare_audio_buffer -> nan_to_num, _to_mono, _normalize_audio) fused with the sample-format
 // conversion that libsndfile performs for the reference's librosa.load (PCM16 -> x / 32768).
 //
-//   k_prepare_convert    raw interleaved samples -> float32, non-finite -> 0, channel mean in float32
-//                        with numpy's summation order, mono samples written out, per-clip max |x|
-//                        gathered with an integer atomicMax on the float bit pattern
+//   k_prepare_convert    raw interleaved samples -> float32, channel mean in float32 with numpy's
+//                        summation order, non-finite -> 0, mono samples written out, per-clip max |x|
+//                        gathered with an integer atomicMax on the float bit pattern.  The mean is taken
+//                        on the RAW samples and the scrub applied to the mono signal: that is the order of
+//                        the reference's primary path (librosa.load mixes down with mono=True before
+//                        _prepare_audio_buffer's nan_to_num sees the data, audio_utils.py:104-110), so a
+//                        NaN or inf in one channel zeroes that frame.
 //   k_prepare_normalise  x / peak (IEEE float32 division, as numpy divides the array by the scalar);
 //                        an all-zero clip stays zero
 // Both are plain HBM streams: 2 B (PCM16) or 4 B per input sample read, 4 B written, then 4 + 4.
@@ -28,9 +32,10 @@ __device__ __forceinline__ float prep_sample(const unsigned char* __restrict__ r
         const short v = reinterpret_cast<const short*>(raw)[idx];
         return static_cast<float>(v) * (1.0f / 32768.0f);   // exact: power-of-two scale of a 16-bit integer
     }
-    const float x = reinterpret_cast<const float*>(raw)[idx];
-    return (fabsf(x) <= 3.4028234663852886e38f) ? x : 0.0f;   // NaN and +-inf -> 0 (np.nan_to_num)
+    return reinterpret_cast<const float*>(raw)[idx];
 }
+// NaN and +-inf -> 0 (np.nan_to_num with nan = posinf = neginf = 0)
+__device__ __forceinline__ float prep_scrub(float x) { return (fabsf(x) <= 3.4028234663852886e38f) ? x : 0.0f; }
 
 // np.add.reduce over a contiguous float32 run of n < 128 elements (numpy's pairwise_sum)
 template <int kFormat>
@@ -66,9 +71,9 @@ __global__ __launch_bounds__(256) void k_prepare_convert(const unsigned char* __
     for (long long f = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; f < c.frames; f += stride) {
         float x;
         if (c.channels == 1) {
-            x = prep_sample<kFormat>(base, f);
+            x = prep_scrub(prep_sample<kFormat>(base, f));
         } else {
-            x = prep_channel_sum<kFormat>(base, f * c.channels, c.channels) / static_cast<float>(c.channels);
+            x = prep_scrub(prep_channel_sum<kFormat>(base, f * c.channels, c.channels) / static_cast<float>(c.channels));
         }
         dst[f] = x;
         peak = fmaxf(peak, fabsf(x));

@@ -32,7 +32,8 @@ from numpy.typing import NDArray
 
 from .audio_io import AudioIntegrityError, read_audio_file, read_raw_clip
 from .handcrafted import HandcraftedBackend
-from .types import FAST_PATH_FLAGS, AudioReadConfig, FeatureFlags
+from .types import (AudioReadConfig, FeatureFlags, coerce_feature_flags, default_feature_flags,
+                    require_accelerated)
 
 logger = logging.getLogger(__name__)
 
@@ -49,10 +50,13 @@ RAVDESS_EMOTIONS: Mapping[str, str] = MappingProxyType({
 
 @dataclass(frozen=True)
 class LoaderSettings:
-    """The settings this path reads from the reference's ``AppConfig`` (same defaults):
-    ``dataset.glob_pattern``, ``emotions``, ``training.{test_size,random_state,stratify_split}``,
-    ``data_loader.{max_workers,max_failed_file_ratio}``, ``models.num_cores``, ``feature_flags``,
-    ``audio_read`` (config/schema.py:243-289)."""
+    """Flat form of the settings this path reads (same defaults as the reference's ``AppConfig``,
+    config/schema.py:243-312).  Every function here also accepts the reference's nested ``AppConfig``
+    itself (or anything shaped like it): see :func:`resolve_loader_settings`.
+
+    ``feature_flags`` defaults to what ``None`` means everywhere else in the package
+    (``types.default_feature_flags``): the reference's 193-dim flags, which raise ``NotImplementedError``
+    at extraction unless ``SERHIP_DEFAULT_FLAGS=fast187`` -- pass ``FeatureFlags(tonnetz=False)``."""
 
     dataset_folder: Path = Path("ser/dataset/ravdess")
     subfolder_prefix: str = "Actor_*"
@@ -64,12 +68,75 @@ class LoaderSettings:
     max_workers: int = 8
     num_cores: int = field(default_factory=lambda: os.cpu_count() or 1)
     max_failed_file_ratio: float = 0.01
-    feature_flags: FeatureFlags = FAST_PATH_FLAGS
+    feature_flags: FeatureFlags = field(default_factory=default_feature_flags)
     audio_read: AudioReadConfig = field(default_factory=AudioReadConfig)
 
     @property
     def glob_pattern(self) -> str:
         return str(Path(self.dataset_folder) / self.subfolder_prefix / self.extension)
+
+
+class ResolvedLoaderSettings(NamedTuple):
+    """What the loader needs, whichever settings object it was given."""
+
+    glob_pattern: str
+    emotions: Mapping[str, str]
+    test_size: float
+    random_state: int
+    stratify_split: bool
+    max_workers: int
+    num_cores: int
+    max_failed_file_ratio: float
+    feature_flags: FeatureFlags
+    audio_read: AudioReadConfig
+
+
+def _audio_read_of(obj) -> AudioReadConfig:
+    if isinstance(obj, AudioReadConfig):
+        return obj
+    if obj is None:
+        return AudioReadConfig()
+    return AudioReadConfig(max_retries=int(obj.max_retries), retry_delay_seconds=float(obj.retry_delay_seconds))
+
+
+def resolve_loader_settings(settings) -> ResolvedLoaderSettings:
+    """Read the loader's settings from ``None`` (defaults), a flat :class:`LoaderSettings`, or an object
+    shaped like the reference's ``AppConfig`` -- exactly the attributes ``_load_data_for_settings`` and
+    ``load_checked_fast_data`` read there (data_loader.py:349-372,483-501): ``dataset.glob_pattern``,
+    ``emotions``, ``training.{test_size, random_state, stratify_split}``,
+    ``data_loader.{max_workers, max_failed_file_ratio}``, ``models.num_cores``, ``feature_flags``,
+    ``audio_read``.  The reference's own dataclasses are read by attribute, never imported."""
+    if settings is None:
+        settings = LoaderSettings()
+    if isinstance(settings, ResolvedLoaderSettings):
+        return settings
+    if hasattr(settings, "training") and hasattr(settings, "dataset"):   # AppConfig-shaped
+        loader = getattr(settings, "data_loader", None)
+        models = getattr(settings, "models", None)
+        return ResolvedLoaderSettings(
+            glob_pattern=str(settings.dataset.glob_pattern),
+            emotions=dict(settings.emotions),
+            test_size=float(settings.training.test_size),
+            random_state=int(settings.training.random_state),
+            stratify_split=bool(settings.training.stratify_split),
+            max_workers=int(getattr(loader, "max_workers", 8)),
+            num_cores=int(getattr(models, "num_cores", 1)),
+            max_failed_file_ratio=float(getattr(loader, "max_failed_file_ratio", 0.01)),
+            feature_flags=coerce_feature_flags(settings.feature_flags),
+            audio_read=_audio_read_of(getattr(settings, "audio_read", None)),
+        )
+    return ResolvedLoaderSettings(
+        glob_pattern=str(settings.glob_pattern),
+        emotions=settings.emotions,
+        test_size=float(settings.test_size),
+        random_state=int(settings.random_state),
+        stratify_split=bool(settings.stratify_split),
+        max_workers=int(settings.max_workers),
+        num_cores=int(settings.num_cores),
+        max_failed_file_ratio=float(settings.max_failed_file_ratio),
+        feature_flags=coerce_feature_flags(settings.feature_flags),
+        audio_read=_audio_read_of(settings.audio_read),
+    )
 
 
 class ProcessFileResult(NamedTuple):
@@ -121,8 +188,8 @@ def process_file(file: str, observed_emotions: Collection[str], emotion_map: Map
             feature_flags, audio_read_config = settings.feature_flags, settings.audio_read
         if feature_flags is None or audio_read_config is None:
             raise ValueError("process_file requires either settings or explicit feature extraction config.")
-        audio, sample_rate = read_audio_file(file, audio_read_config=audio_read_config)
-        vector = HandcraftedBackend(feature_flags=feature_flags).extract_vector(audio, sample_rate)
+        audio, sample_rate = read_audio_file(file, audio_read_config=_audio_read_of(audio_read_config))
+        vector = HandcraftedBackend(feature_flags=coerce_feature_flags(feature_flags)).extract_vector(audio, sample_rate)
         return ProcessFileResult(sample=(np.asarray(vector, dtype=np.float64), emotion), error=None)
     except Exception as err:
         return ProcessFileResult(sample=None, error=f"Failed to process file {file}: {err}")
@@ -149,10 +216,56 @@ def _read_one(job):
         return None, None, err
 
 
+#: a slab of jobs is read, packed and featurised together; its decoded size is bounded so that a large
+#: corpus streams through host memory and HBM instead of being resident twice (override with
+#: ``SERHIP_SLAB_BYTES``).  1 GiB of PCM16 is ~9 h of 16 kHz audio: large enough to fill the GPU.
+DEFAULT_SLAB_BYTES = 1 << 30
+
+
+def _slab_bytes() -> int:
+    try:
+        return max(1 << 20, int(os.environ.get("SERHIP_SLAB_BYTES", DEFAULT_SLAB_BYTES)))
+    except ValueError:
+        return DEFAULT_SLAB_BYTES
+
+
+def _job_slabs(jobs, budget: int):
+    """Cut the job list into consecutive index ranges whose files add up to about ``budget`` bytes on
+    disk (a missing file counts as nothing: it fails when read)."""
+    first, used = 0, 0
+    for i, (path, _s, _d) in enumerate(jobs):
+        try:
+            size = os.path.getsize(path)
+        except OSError:
+            size = 0
+        if i > first and used + size > budget:
+            yield first, i
+            first, used = i, 0
+        used += size
+    if first < len(jobs):
+        yield first, len(jobs)
+
+
+def _bisecting(indices: list[int], run, on_error) -> None:
+    """``run(indices)`` for the whole group; when that raises, halve the group and try again, down to
+    single items, so that one bad clip (or one batch too large for HBM) costs only itself: the
+    reference loses exactly the offending file (data_loader.py:296-297), not its neighbours."""
+    try:
+        run(indices)
+    except Exception as err:
+        if len(indices) == 1:
+            on_error(indices[0], err)
+            return
+        mid = len(indices) // 2
+        _bisecting(indices[:mid], run, on_error)
+        _bisecting(indices[mid:], run, on_error)
+
+
 def _featurize_raw_group(clips, rate: int, sample_format: str, feature_flags: FeatureFlags):
     """One GPU batch for raw clips of one (sample rate, sample format): payload bytes are packed
     back to back (16-byte aligned), converted / mixed down / peak-normalised on the device
-    (``serhip_prepare_audio``) and featurised from there -- the samples never exist on the host."""
+    (``serhip_prepare_audio``) and featurised from there -- the samples never exist on the host.
+    Returns the ``[len(clips), D]`` float32 DEVICE tensor."""
     from . import dsp
     from .engine import get_engine
 
@@ -167,102 +280,153 @@ def _featurize_raw_group(clips, rate: int, sample_format: str, feature_flags: Fe
     engine = get_engine()
     audio, out_off, frames = engine.prepare_audio(packed, sample_format, offsets, [c.frames for c in clips],
                                                   [c.channels for c in clips])
-    return engine.features(audio, out_off, frames, rate, feature_flags).cpu().numpy().astype(np.float64)
+    return engine.features(audio, out_off, frames, rate, feature_flags)
+
+
+def _featurize_host_group(clips, rate: int, feature_flags: FeatureFlags):
+    """One GPU batch for clips decoded and prepared on the host; ``[len(clips), D]`` float32 device tensor."""
+    from . import dsp
+    from .engine import get_engine
+
+    dsp.check_flags_for_rate(feature_flags, rate)
+    lengths = np.asarray([c.size for c in clips], dtype=np.int64)
+    offsets = np.concatenate(([0], np.cumsum(lengths)[:-1])).astype(np.int64)
+    return get_engine().features(np.concatenate(clips), offsets, lengths, rate, feature_flags)
+
+
+def featurize_audio_jobs_device(jobs: Sequence[tuple[str, float | None, float | None]], *,
+                                feature_flags: FeatureFlags, audio_read_config: AudioReadConfig, workers: int = 8,
+                                device_prepare: bool = True):
+    """Device-resident form of :func:`featurize_audio_jobs`: ``(matrix, errors)`` with ``matrix`` a
+    ``[n_jobs, D]`` float32 torch tensor on the engine's GPU (failed rows NaN).  The multi-GPU gather
+    takes this tensor as it is -- features never visit the host on their way into the collective."""
+    from .engine import get_engine
+
+    require_accelerated(feature_flags)
+    n = len(jobs)
+    dim = feature_flags.width()
+    engine = get_engine()
+    torch = engine._torch
+    matrix = torch.full((n, dim), float("nan"), dtype=torch.float32, device=engine.device)
+    errors: list[Exception | None] = [None] * n
+    if n == 0 or dim == 0:
+        return matrix, errors
+
+    def fail(i: int, err: Exception) -> None:
+        errors[i] = err
+
+    for lo, hi in _job_slabs(jobs, _slab_bytes()):
+        packed = [(p, s, d, audio_read_config, device_prepare) for p, s, d in jobs[lo:hi]]
+        if workers > 1 and len(packed) > 1:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                decoded = list(pool.map(_read_one, packed))
+        else:
+            decoded = [_read_one(j) for j in packed]
+        raw_groups: dict[tuple[int, str], list[int]] = {}
+        host_groups: dict[int, list[int]] = {}
+        for k, (kind, value, err) in enumerate(decoded):
+            if kind is None:
+                errors[lo + k] = err
+            elif kind == "raw":
+                raw_groups.setdefault((value.sample_rate, value.sample_format), []).append(k)
+            else:
+                try:   # per-clip validation errors must not poison the batch
+                    from .dsp import validate_signal
+
+                    validate_signal(value[0], int(value[1]))
+                    host_groups.setdefault(int(value[1]), []).append(k)
+                except Exception as err2:
+                    errors[lo + k] = err2
+        for (rate, sample_format), ks in raw_groups.items():
+            def run_raw(sub, rate=rate, sample_format=sample_format):
+                rows = _featurize_raw_group([decoded[k][1] for k in sub], rate, sample_format, feature_flags)
+                matrix[torch.as_tensor([lo + k for k in sub], device=engine.device)] = rows
+            _bisecting(ks, run_raw, lambda k, err: fail(lo + k, err))
+        for rate, ks in host_groups.items():
+            def run_host(sub, rate=rate):
+                rows = _featurize_host_group([decoded[k][1][0] for k in sub], rate, feature_flags)
+                matrix[torch.as_tensor([lo + k for k in sub], device=engine.device)] = rows
+            _bisecting(ks, run_host, lambda k, err: fail(lo + k, err))
+        del decoded
+    return matrix, errors
 
 
 def featurize_audio_jobs(jobs: Sequence[tuple[str, float | None, float | None]], *, feature_flags: FeatureFlags,
                          audio_read_config: AudioReadConfig, workers: int = 8, device_prepare: bool = True):
     """Read ``(path, start_seconds, duration_seconds)`` jobs on host threads and featurise every
-    readable clip in one GPU batch per (sample rate, sample format).
+    readable clip on the GPU, one batch per (sample rate, sample format) and slab of ~1 GiB of files.
 
     With ``device_prepare`` (default) PCM16 / float32 WAVE payloads go to the GPU as raw bytes and
     ``_prepare_audio_buffer`` (audio_utils.py:28-60) runs there; other encodings are decoded and
     prepared on the host as before.  Returns ``(matrix [n_jobs, D] float64, errors)`` where
-    ``errors[i]`` is None or the exception of job i (its matrix row is NaN)."""
-    n = len(jobs)
-    dim = feature_flags.width()
-    matrix = np.full((n, dim), np.nan, dtype=np.float64)
-    errors: list[Exception | None] = [None] * n
-    if n == 0:
-        return matrix, errors
-    if feature_flags.tonnetz:
-        raise NotImplementedError("tonnetz features are outside the accelerated path; use FeatureFlags(tonnetz=False)")
-    packed = [(p, s, d, audio_read_config, device_prepare) for p, s, d in jobs]
-    if workers > 1 and n > 1:
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            decoded = list(pool.map(_read_one, packed))
-    else:
-        decoded = [_read_one(j) for j in packed]
-    raw_groups: dict[tuple[int, str], list[int]] = {}
-    by_rate: dict[int, list[int]] = {}
-    for i, (kind, value, err) in enumerate(decoded):
-        if kind is None:
-            errors[i] = err
-        elif kind == "raw":
-            raw_groups.setdefault((value.sample_rate, value.sample_format), []).append(i)
-        else:
-            by_rate.setdefault(int(value[1]), []).append(i)
-    for (rate, sample_format), idxs in raw_groups.items():
-        try:
-            matrix[idxs] = _featurize_raw_group([decoded[i][1] for i in idxs], rate, sample_format, feature_flags)
-        except Exception as err:
-            for i in idxs:
-                errors[i] = err
-    backend = HandcraftedBackend(feature_flags=feature_flags)
-    for rate, idxs in by_rate.items():
-        clips, good = [], []
-        for i in idxs:
-            clip = decoded[i][1][0]
-            try:  # per-clip validation errors must not poison the batch
-                from .dsp import validate_signal
-
-                validate_signal(clip, rate)
-                clips.append(clip)
-                good.append(i)
-            except Exception as err:
-                errors[i] = err
-        if not clips:
-            continue
-        try:
-            matrix[good] = backend.extract_vectors(clips, rate)
-        except Exception as err:
-            for i in good:
-                errors[i] = err
-    return matrix, errors
+    ``errors[i]`` is None or the exception of job i (its matrix row is NaN).  A batch that fails as a
+    whole is retried in halves, so one bad clip is reported alone."""
+    require_accelerated(feature_flags)
+    if len(jobs) == 0 or feature_flags.width() == 0:
+        return np.full((len(jobs), feature_flags.width()), np.nan, dtype=np.float64), [None] * len(jobs)
+    matrix, errors = featurize_audio_jobs_device(jobs, feature_flags=feature_flags,
+                                                 audio_read_config=audio_read_config, workers=workers,
+                                                 device_prepare=device_prepare)
+    return matrix.cpu().numpy().astype(np.float64), errors
 
 
-def featurize_files(files: Sequence[str], *, settings: LoaderSettings | None = None, distributed: bool = False):
-    """Feature matrix for whole files (training vectors).  With ``distributed=True`` and an initialised
-    ``torch.distributed`` group, each rank featurises its contiguous shard and the rows are all-gathered."""
-    active = settings if settings is not None else LoaderSettings()
+def featurize_files(files: Sequence[str], *, settings=None, distributed: bool = False, featurize_jobs=None):
+    """Feature matrix for whole files (training vectors): ``(matrix [n, D] float64, errors)``.
+
+    With ``distributed=True`` and an initialised ``torch.distributed`` group, rank r featurises the
+    contiguous shard ``shard_range(n, r, world)`` of ``files`` and one ``all_gather_into_tensor`` (RCCL
+    under the ``nccl`` backend, float32 rows straight from the feature kernels' output tensor) assembles
+    the matrix on every rank.  A row that failed anywhere is NaN on every rank; its owner reports the
+    exception, the other ranks a ``RuntimeError`` naming the owner.
+
+    ``featurize_jobs`` replaces :func:`featurize_audio_jobs_device` (same signature; may return a numpy
+    array or a tensor on any device) -- the CPU test-suite drives the sharding and the gather with it."""
+    active = resolve_loader_settings(settings)
     files = list(files)
-    workers = _resolve_worker_count(active.num_cores, active.max_workers, len(files))
+    run = featurize_jobs if featurize_jobs is not None else featurize_audio_jobs_device
     if not distributed:
-        return featurize_audio_jobs([(f, None, None) for f in files], feature_flags=active.feature_flags,
-                                    audio_read_config=active.audio_read, workers=workers)
+        workers = _resolve_worker_count(active.num_cores, active.max_workers, len(files))
+        matrix, errors = run([(f, None, None) for f in files], feature_flags=active.feature_flags,
+                             audio_read_config=active.audio_read, workers=workers)
+        if hasattr(matrix, "cpu"):
+            matrix = matrix.cpu().numpy()
+        return np.asarray(matrix, dtype=np.float64), errors
     import torch
     import torch.distributed as dist
 
-    from .distributed import all_gather_rows, shard_range
+    from .distributed import all_gather_rows, shard_bounds
 
     world, rank = dist.get_world_size(), dist.get_rank()
-    lo, hi = shard_range(len(files), rank, world)
-    local, local_err = featurize_audio_jobs([(f, None, None) for f in files[lo:hi]],
-                                            feature_flags=active.feature_flags,
-                                            audio_read_config=active.audio_read, workers=workers)
-    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    full = all_gather_rows(torch.from_numpy(local).to(device), len(files)).cpu().numpy()
+    bounds = shard_bounds(len(files), world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    workers = _resolve_worker_count(active.num_cores, active.max_workers, hi - lo)
+    local, local_err = run([(f, None, None) for f in files[lo:hi]], feature_flags=active.feature_flags,
+                           audio_read_config=active.audio_read, workers=workers)
+    if not isinstance(local, torch.Tensor):
+        local = torch.from_numpy(np.ascontiguousarray(np.asarray(local, dtype=np.float32)))
+    local = local.to(torch.float32)
+    if dist.get_backend() == "nccl":
+        if not local.is_cuda:
+            local = local.cuda()
+    else:
+        local = local.cpu()   # gloo (CPU tests, rehearsals)
+    full = all_gather_rows(local, len(files)).cpu().numpy().astype(np.float64)
     errors: list[Exception | None] = [None] * len(files)
+    owner = np.searchsorted(bounds, np.arange(len(files)), side="right") - 1
     for i in np.flatnonzero(np.isnan(full).any(axis=1)):
-        errors[int(i)] = local_err[int(i) - lo] if lo <= i < hi else RuntimeError("extraction failed on another rank")
+        i = int(i)
+        errors[i] = local_err[i - lo] if lo <= i < hi else RuntimeError(
+            f"feature extraction of {files[i]} failed on rank {int(owner[i])}")
     return full, errors
 
 
-def load_data(test_size: float | None = None, *, settings: LoaderSettings | None = None) -> DataSplit | None:
-    """Glob the dataset, featurise on the GPU and split -> ``(x_train, x_test, y_train, y_test)`` or None."""
+def load_data(test_size: float | None = None, *, settings=None) -> DataSplit | None:
+    """Glob the dataset, featurise on the GPU and split -> ``(x_train, x_test, y_train, y_test)`` or None.
+    Counterpart of ``load_data`` / ``_load_data_for_settings`` (data_loader.py:335-464); ``settings`` may be
+    the reference's ``AppConfig`` (see :func:`resolve_loader_settings`)."""
     from sklearn.model_selection import train_test_split
 
-    active = settings if settings is not None else LoaderSettings()
+    active = resolve_loader_settings(settings)
     observed = set(active.emotions.values())
     resolved_test_size = active.test_size if test_size is None else test_size
     if not 0.0 < resolved_test_size < 1.0:
@@ -320,24 +484,54 @@ def load_data(test_size: float | None = None, *, settings: LoaderSettings | None
             [str(v) for v in split[2]], [str(v) for v in split[3]])
 
 
-def load_checked_fast_data(*, train_utterances: Sequence, test_utterances: Sequence, settings: LoaderSettings,
-                           handle_sample_failure: Callable[[object, Exception], bool] | None = None
-                           ) -> DataSplit | None:
-    """Fast features for readiness-checked utterances (reference: data_loader.py:467-535).
+def default_split_utterances(*, samples: Sequence, settings, logger=None):
+    """Stand-in for the reference's ``split_utterances`` (models/dataset_splitting.py:254-364), which
+    is dataset governance (manifest splits, speaker grouping, salted hashing) and stays in ``ser``:
+    inject it through ``load_checked_fast_data(split_utterances=...)``.  This default keeps the call
+    shape ``(samples=, settings=, logger=) -> (train, test, info)`` and does the simplest honest
+    thing: utterances that carry a ``split`` attribute of "train" / "test" ("dev" counts as test) keep it;
+    otherwise a seeded, label-stratified ``train_test_split`` with the settings' ``test_size`` and
+    ``random_state`` (non-stratified when stratification is impossible)."""
+    from sklearn.model_selection import train_test_split
 
-    The reference splits inside (``split_utterances``, dataset governance, out of scope); here the
-    caller passes the two partitions.  An utterance is any object with ``audio_path``,
-    ``start_seconds``, ``duration_seconds``, ``sample_id`` and ``require_label()``.  Each partition is
-    one GPU batch; per-sample failures go through ``handle_sample_failure`` exactly as in the reference
-    (True = skip the sample, otherwise the error is raised)."""
+    samples = list(samples)
+    tagged = [str(getattr(u, "split", "") or "").lower() for u in samples]
+    if samples and all(t in ("train", "test", "dev") for t in tagged):
+        train = [u for u, t in zip(samples, tagged) if t == "train"]
+        test = [u for u, t in zip(samples, tagged) if t != "train"]
+        return train, test, {"strategy": "manifest"}
+    active = resolve_loader_settings(settings)
+    labels = [u.require_label() for u in samples]
+    order = list(range(len(samples)))
+    try:
+        tr, te = train_test_split(order, test_size=active.test_size, random_state=active.random_state,
+                                  stratify=labels if active.stratify_split else None)
+    except ValueError as err:
+        if logger is not None:
+            logger.warning("Stratified split failed (%s). Falling back to non-stratified split.", err)
+        tr, te = train_test_split(order, test_size=active.test_size, random_state=active.random_state, stratify=None)
+    return [samples[i] for i in sorted(tr)], [samples[i] for i in sorted(te)], {"strategy": "stratified_shuffle"}
+
+
+def load_checked_partitions(*, train_utterances: Sequence, test_utterances: Sequence, settings,
+                            handle_sample_failure: Callable[[object, Exception], bool] | None = None
+                            ) -> DataSplit | None:
+    """Fast features for two already-split partitions of readiness-checked utterances: the body of the
+    reference's ``load_checked_fast_data`` after its ``split_utterances`` call (data_loader.py:483-535).
+
+    An utterance is any object with ``audio_path``, ``start_seconds``, ``duration_seconds``,
+    ``sample_id`` and ``require_label()``.  Each partition is ONE GPU batch (the reference extracts
+    serially); per-sample failures go through ``handle_sample_failure`` exactly as in the reference
+    (True = skip the sample, otherwise the error is raised), in partition order."""
     if not train_utterances and not test_utterances:
         return None
+    active = resolve_loader_settings(settings)
 
     def extract(partition: Sequence):
         jobs = [(str(u.audio_path), u.start_seconds, u.duration_seconds) for u in partition]
-        matrix, failures = featurize_audio_jobs(jobs, feature_flags=settings.feature_flags,
-                                                audio_read_config=settings.audio_read,
-                                                workers=_resolve_worker_count(settings.num_cores, settings.max_workers,
+        matrix, failures = featurize_audio_jobs(jobs, feature_flags=active.feature_flags,
+                                                audio_read_config=active.audio_read,
+                                                workers=_resolve_worker_count(active.num_cores, active.max_workers,
                                                                               len(jobs)))
         rows, labels = [], []
         for utterance, row, failure in zip(partition, matrix, failures):
@@ -358,3 +552,23 @@ def load_checked_fast_data(*, train_utterances: Sequence, test_utterances: Seque
     if len(set(y_train)) < 2:
         raise RuntimeError("Fast checked preparation left fewer than two training classes.")
     return x_train, x_test, y_train, y_test
+
+
+def load_checked_fast_data(*, utterances: Sequence, settings,
+                           handle_sample_failure: Callable[[object, Exception], bool] | None = None,
+                           split_utterances: Callable | None = None) -> DataSplit | None:
+    """Drop-in for the reference's ``load_checked_fast_data(*, utterances, settings,
+    handle_sample_failure=None)`` (data_loader.py:467-535), i.e. for
+    ``FastTrainingHooks.load_checked_data`` as wired at models/training_entrypoints.py:70-80.
+
+    ``settings`` is the reference's ``AppConfig`` (or a :class:`LoaderSettings`).  ``split_utterances``
+    is the one extra, optional argument: the splitter, called as the reference calls its own --
+    ``split_utterances(samples=list(utterances), settings=settings, logger=logger)`` returning
+    ``(train, test, info)``.  Pass ``ser._internal.models.dataset_splitting.split_utterances`` to
+    get the reference's partitions; the default is :func:`default_split_utterances`."""
+    if not utterances:
+        return None
+    splitter = split_utterances if split_utterances is not None else default_split_utterances
+    train_utterances, test_utterances, _ = splitter(samples=list(utterances), settings=settings, logger=logger)
+    return load_checked_partitions(train_utterances=train_utterances, test_utterances=test_utterances,
+                                   settings=settings, handle_sample_failure=handle_sample_failure)

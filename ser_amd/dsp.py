@@ -14,7 +14,7 @@ import numpy as np
 from numpy.typing import NDArray
 
 from .engine import get_engine
-from .types import FAST_PATH_FLAGS, FeatureFlags, FeatureVector
+from .types import FeatureFlags, FeatureVector, coerce_feature_flags, require_accelerated
 
 logger = logging.getLogger(__name__)
 
@@ -56,17 +56,15 @@ def extract_feature_from_signal(
 ) -> FeatureVector:
     """Extract the configured features from an in-memory mono signal (float64 vector).
 
-    ``feature_flags=None`` selects the accelerated 187-dim configuration
-    (``FeatureFlags(tonnetz=False)``); the reference's own default additionally
-    enables tonnetz, which this package does not implement.
+    ``feature_flags=None`` means what it means in the reference: ``FeatureFlags()`` with tonnetz on
+    (193 dims, dsp.py:92).  Tonnetz is not implemented here, so that default raises
+    ``NotImplementedError`` (after the input validation, like any other extraction failure) unless
+    ``SERHIP_DEFAULT_FLAGS=fast187`` is set; pass ``FeatureFlags(tonnetz=False)`` for the 187-dim vector.
     """
-    flags = feature_flags if feature_flags is not None else FAST_PATH_FLAGS
+    flags = coerce_feature_flags(feature_flags)
     prepared = validate_signal(audio, sample_rate)
     try:
-        if flags.tonnetz:
-            raise NotImplementedError(
-                "tonnetz features are outside the accelerated path; use FeatureFlags(tonnetz=False)"
-            )
+        require_accelerated(flags)
         if flags.width() == 0:
             return np.empty(0, dtype=np.float64)
         check_flags_for_rate(flags, sample_rate)

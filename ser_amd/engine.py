@@ -16,7 +16,7 @@ from ctypes import POINTER, c_int32, c_int64, c_void_p
 import numpy as np
 
 from . import _native
-from .types import FeatureFlags
+from .types import FeatureFlags, require_accelerated
 
 _engines: dict[tuple[int, int], "FeatureEngine"] = {}
 _engines_lock = threading.Lock()
@@ -89,11 +89,7 @@ class FeatureEngine:
         ``audio`` is a 1-D float32 numpy array or torch tensor (moved to the GPU if
         needed); ``seg_offset`` / ``seg_len`` are host integer sequences.
         """
-        if flags.tonnetz:
-            raise NotImplementedError(
-                "tonnetz features (HPSS + constant-Q chroma) are outside the accelerated path; "
-                "use FeatureFlags(tonnetz=False)"
-            )
+        require_accelerated(flags)
         torch = self._torch
         audio_dev = self.to_device(audio)
         if audio_dev.dim() != 1:

@@ -4,8 +4,11 @@
 ``extract_feature_from_signal`` follow
 ``ser/_internal/features/feature_extractor.py:106-179``; ``settings`` is any object
 with ``feature_flags`` and ``audio_read`` attributes (the reference's ``AppConfig``
-qualifies).  ``settings=None`` uses :data:`DEFAULT_SETTINGS` -- the 187-dim fast-path
-flags -- instead of reloading an environment snapshot.
+qualifies).  ``settings=None`` means the reference's defaults (``FeatureFlags()`` with tonnetz on,
+``AudioReadConfig()``) instead of reloading an environment snapshot; because tonnetz is not
+implemented, that default raises ``NotImplementedError`` unless ``SERHIP_DEFAULT_FLAGS=fast187``
+is set (``ser_amd.types.default_feature_flags``).  Pass ``FeatureSettings(FeatureFlags(tonnetz=False))``
+or the application's own settings object with tonnetz switched off.
 """
 
 from __future__ import annotations
@@ -19,7 +22,7 @@ from numpy.typing import NDArray
 from . import dsp
 from .audio_io import read_audio_file
 from .handcrafted import HandcraftedBackend
-from .types import FAST_PATH_FLAGS, AudioReadConfig, FeatureFlags, FeatureFrame, FeatureVector
+from .types import AudioReadConfig, FeatureFlags, FeatureFrame, FeatureVector, coerce_feature_flags
 
 logger = logging.getLogger(__name__)
 
@@ -28,15 +31,22 @@ logger = logging.getLogger(__name__)
 class FeatureSettings:
     """The two settings the path reads from the reference's ``AppConfig``."""
 
-    feature_flags: FeatureFlags = FAST_PATH_FLAGS
+    feature_flags: FeatureFlags = field(default_factory=FeatureFlags)
     audio_read: AudioReadConfig = field(default_factory=AudioReadConfig)
 
 
-DEFAULT_SETTINGS = FeatureSettings()
-
-
 def _resolve(settings) -> FeatureSettings:
-    return settings if settings is not None else DEFAULT_SETTINGS
+    """``settings`` may be None, a :class:`FeatureSettings`, or any object with ``feature_flags`` and
+    ``audio_read`` attributes (the reference's ``AppConfig``; its dataclasses are read by attribute)."""
+    if settings is None:
+        return FeatureSettings(feature_flags=coerce_feature_flags(None))
+    audio_read = getattr(settings, "audio_read", None)
+    if not isinstance(audio_read, AudioReadConfig):
+        audio_read = AudioReadConfig(
+            max_retries=int(getattr(audio_read, "max_retries", 3)),
+            retry_delay_seconds=float(getattr(audio_read, "retry_delay_seconds", 1.0)),
+        )
+    return FeatureSettings(feature_flags=coerce_feature_flags(settings.feature_flags), audio_read=audio_read)
 
 
 def extract_feature_from_signal(audio: NDArray[np.float32], sample_rate: int, *, settings=None) -> FeatureVector:

@@ -20,12 +20,13 @@ from numpy.typing import NDArray
 from . import dsp
 from .engine import get_engine
 from .types import (
-    FAST_PATH_FLAGS,
     EncodedSequence,
     FeatureFlags,
     FeatureMatrix,
     FeatureVector,
     PoolingWindow,
+    coerce_feature_flags,
+    require_accelerated,
 )
 
 
@@ -54,7 +55,9 @@ class HandcraftedBackend:
             raise ValueError("frame_stride_seconds must be greater than zero.")
         self._frame_size_seconds = frame_size_seconds
         self._frame_stride_seconds = frame_stride_seconds
-        self._feature_flags = feature_flags if feature_flags is not None else FAST_PATH_FLAGS
+        # None is the reference's default (tonnetz on, feature_dim 193, handcrafted.py:38): extraction then
+        # raises NotImplementedError unless SERHIP_DEFAULT_FLAGS=fast187 (types.default_feature_flags)
+        self._feature_flags = coerce_feature_flags(feature_flags)
 
     @property
     def backend_id(self) -> str:
@@ -105,6 +108,7 @@ class HandcraftedBackend:
     def extract_vectors(self, audios: Sequence[NDArray[np.float32]], sample_rate: int) -> FeatureMatrix:
         """``[len(audios), D]`` float64: one vector per whole clip, one GPU batch for all clips."""
         prepared = [dsp.validate_signal(a, sample_rate) for a in audios]
+        require_accelerated(self._feature_flags)
         if self._feature_flags.width() == 0 or not prepared:
             return np.empty((len(prepared), self._feature_flags.width()), dtype=np.float64)
         dsp.check_flags_for_rate(self._feature_flags, sample_rate)
@@ -130,10 +134,7 @@ class HandcraftedBackend:
                                                 self._frame_stride_seconds))
         if not prepared:
             return []
-        if self._feature_flags.tonnetz:
-            raise NotImplementedError(
-                "tonnetz features are outside the accelerated path; use FeatureFlags(tonnetz=False)"
-            )
+        require_accelerated(self._feature_flags)
         dsp.check_flags_for_rate(self._feature_flags, sample_rate)
         base = np.concatenate(([0], np.cumsum([a.size for a in prepared])[:-1])).astype(np.int64)
         offsets = np.concatenate([b + s for b, (s, _) in zip(base, bounds)])

@@ -1,17 +1,31 @@
-"""Prepared-feature cache: the ``.npz`` payload ``ser --train --prepare-only`` publishes and
-``--prepared-plan`` consumes.
+"""Prepared-feature cache: the ``.npz`` file that ``ser --train --prepare-only`` publishes and
+``ser --train --prepared-plan`` consumes, so GPU-built feature matrices
+can feed the reference's trainer.
 
-Same container as ``write_prepared_feature_payload`` / ``read_prepared_feature_payload``
-(``ser/_internal/models/training_orchestration.py:842-973``): ``np.savez_compressed`` with keys
-``x_train, x_dev, x_test`` (float64, 2-D), ``y_train, y_dev, y_test`` (``np.str_`` 1-D) and
-``metadata_json`` (0-d string, compact sorted-key JSON); written to a temp file in the destination
-directory, fsynced and ``os.replace``d; read with ``allow_pickle=False``.  The reference's reader also
-cross-checks the payload against its digest-protected plan ledger (governance, out of scope); the
-structural checks are reproduced here with the reference's messages.
+Written from the FORMAT, which is what the reference's payload functions define
+(``ser/_internal/models/training_orchestration.py:842-973``; file name from
+``training_readiness.py:880-882``, cache namespace ``"fast_features"``):
+
+=================  =======================================================================
+entry              content
+=================  =======================================================================
+``x_train``        float64 ``[n_train, D]``
+``x_dev``          float64 ``[n_dev, D]``   (may have 0 rows)
+``x_test``         float64 ``[n_test, D]``
+``y_train`` ...    numpy unicode ``[n]``, one non-blank label per row of the matching matrix
+``metadata_json``  0-d numpy unicode: compact JSON object with sorted keys
+=================  =======================================================================
+
+compressed ``.npz`` (``np.savez_compressed``), no pickled objects, replaced atomically.  The
+reference's reader additionally checks the file against its digest-protected plan ledger
+(governance, out of scope); here ``feature_dtype`` / ``feature_shape`` stand in for the plan.
+
+The module is table-driven: :data:`SCHEMA` lists the entries once and both directions walk it.
 """
 
 from __future__ import annotations
 
+import contextlib
 import json
 import os
 import tempfile
@@ -22,12 +36,19 @@ from typing import NamedTuple
 import numpy as np
 from numpy.typing import NDArray
 
-PAYLOAD_KEYS = frozenset({"x_train", "x_dev", "x_test", "y_train", "y_dev", "y_test", "metadata_json"})
-DEFAULT_FILE_NAME = "prepared-training-fast.npz"   # training_readiness.py:880-882, namespace "fast_features"
+DEFAULT_FILE_NAME = "prepared-training-fast.npz"
+PARTITIONS = ("train", "dev", "test")
+#: entry name -> kind; the order is the order entries are written in
+SCHEMA: tuple[tuple[str, str], ...] = (
+    *((f"x_{p}", "matrix") for p in PARTITIONS),
+    *((f"y_{p}", "labels") for p in PARTITIONS),
+    ("metadata_json", "json"),
+)
+PAYLOAD_KEYS = frozenset(name for name, _ in SCHEMA)
 
 
 class PreparedPlanError(ValueError):
-    """The payload is missing, malformed or inconsistent."""
+    """The payload file is missing, malformed or inconsistent with what was planned."""
 
 
 class PreparedFeaturePayload(NamedTuple):
@@ -41,83 +62,126 @@ class PreparedFeaturePayload(NamedTuple):
 
 
 def serialize_metadata(value):
-    """JSON-safe form of plan metadata (paths -> str, tuples -> lists), like the reference's helper."""
-    if isinstance(value, Mapping):
-        return {str(k): serialize_metadata(v) for k, v in value.items()}
-    if isinstance(value, Path):
-        return str(value)
-    if isinstance(value, (tuple, list)):
-        return [serialize_metadata(v) for v in value]
-    if value is None or isinstance(value, (str, int, float, bool)):
+    """Plan metadata as plain JSON types: mappings -> dicts with string keys, paths -> strings,
+    sequences -> lists; anything else that JSON cannot hold is a ``TypeError``."""
+    if value is None or isinstance(value, (bool, int, float, str)):
         return value
+    if isinstance(value, os.PathLike):
+        return os.fspath(value)
+    if isinstance(value, Mapping):
+        return {str(key): serialize_metadata(item) for key, item in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [serialize_metadata(item) for item in value]
     raise TypeError(f"Unsupported prepared metadata type: {type(value).__name__}")
+
+
+def _encode(kind: str, value) -> np.ndarray:
+    if kind == "matrix":
+        return np.asarray(value, dtype=np.float64)
+    if kind == "labels":
+        return np.asarray([str(label) for label in value], dtype=np.str_)
+    return np.asarray(json.dumps(serialize_metadata(value), sort_keys=True, separators=(",", ":")), dtype=np.str_)
+
+
+@contextlib.contextmanager
+def _replacing(destination: Path):
+    """Yield a binary handle on a sibling temp file; on a clean exit its bytes are flushed to disk
+    and renamed over ``destination`` (readers see the old file or the new one, never a torso); on
+    an exception the temp file is removed and ``destination`` is untouched."""
+    destination.parent.mkdir(parents=True, exist_ok=True)
+    handle = tempfile.NamedTemporaryFile("wb", dir=destination.parent, prefix=f".{destination.name}.",
+                                         suffix=".part", delete=False)
+    try:
+        with handle:
+            yield handle
+            handle.flush()
+            os.fsync(handle.fileno())
+        os.replace(handle.name, destination)
+    except BaseException:
+        with contextlib.suppress(FileNotFoundError):
+            os.unlink(handle.name)
+        raise
 
 
 def write_prepared_feature_payload(path, *, x_train, x_dev, x_test, y_train: Sequence[str], y_dev: Sequence[str],
                                    y_test: Sequence[str], metadata: Mapping[str, object]) -> Path:
-    """Atomically persist reusable features without pickle/object arrays."""
+    """Publish one payload file (same keyword surface as the reference's writer); returns its path."""
+    given = {"x_train": x_train, "x_dev": x_dev, "x_test": x_test, "y_train": y_train, "y_dev": y_dev,
+             "y_test": y_test, "metadata_json": metadata}
+    arrays = {name: _encode(kind, given[name]) for name, kind in SCHEMA}
     destination = Path(path)
-    destination.parent.mkdir(parents=True, exist_ok=True)
-    descriptor, raw_tmp = tempfile.mkstemp(prefix=f".{destination.name}.", dir=destination.parent)
-    tmp_path = Path(raw_tmp)
-    try:
-        with os.fdopen(descriptor, "wb") as handle:
-            np.savez_compressed(
-                handle,
-                x_train=np.asarray(x_train, dtype=np.float64),
-                x_dev=np.asarray(x_dev, dtype=np.float64),
-                x_test=np.asarray(x_test, dtype=np.float64),
-                y_train=np.asarray(list(y_train), dtype=np.str_),
-                y_dev=np.asarray(list(y_dev), dtype=np.str_),
-                y_test=np.asarray(list(y_test), dtype=np.str_),
-                metadata_json=np.asarray(
-                    json.dumps(serialize_metadata(metadata), sort_keys=True, separators=(",", ":")), dtype=np.str_),
-            )
-            handle.flush()
-            os.fsync(handle.fileno())
-        os.replace(tmp_path, destination)
-    finally:
-        tmp_path.unlink(missing_ok=True)
+    with _replacing(destination) as handle:
+        np.savez_compressed(handle, **arrays)
     return destination
+
+
+def _decode_matrix(name: str, arr: np.ndarray, feature_dtype: str) -> NDArray[np.float64]:
+    if arr.dtype.name != feature_dtype:
+        raise PreparedPlanError(f"Prepared payload entry {name} has dtype {arr.dtype.name}, the plan says {feature_dtype}.")
+    if arr.ndim != 2:
+        raise PreparedPlanError(f"Prepared payload entry {name} has {arr.ndim} dimensions, expected a 2-D matrix.")
+    out = np.asarray(arr, dtype=np.float64)
+    if not np.isfinite(out).all():
+        raise PreparedPlanError(f"Prepared payload entry {name} contains non-finite values.")
+    return out
+
+
+def _decode_labels(name: str, arr: np.ndarray) -> list[str]:
+    if arr.ndim != 1 or arr.dtype.kind not in "US":
+        raise PreparedPlanError(f"Prepared payload entry {name} must be a 1-D array of strings.")
+    labels = [str(item) for item in arr.tolist()]
+    blank = sum(1 for label in labels if not label.strip())
+    if blank:
+        raise PreparedPlanError(f"Prepared payload entry {name} holds {blank} blank label(s).")
+    return labels
+
+
+def _decode_json(name: str, arr: np.ndarray) -> dict:
+    if arr.ndim != 0 or arr.dtype.kind not in "US":
+        raise PreparedPlanError(f"Prepared payload entry {name} must be one scalar JSON string.")
+    try:
+        parsed = json.loads(str(arr[()]))
+    except json.JSONDecodeError as error:
+        raise PreparedPlanError(f"Prepared payload entry {name} is not valid JSON: {error}") from error
+    if not isinstance(parsed, dict):
+        raise PreparedPlanError(f"Prepared payload entry {name} must decode to a JSON object.")
+    return parsed
 
 
 def read_prepared_feature_payload(path, *, feature_dtype: str = "float64",
                                   feature_shape: tuple[int, int] | None = None) -> PreparedFeaturePayload:
-    """Read and structurally validate one payload (dtype/shape arguments play the plan's role)."""
+    """Load and validate one payload.  ``feature_shape`` is the planned ``(total rows, D)``."""
     try:
-        with np.load(Path(path), allow_pickle=False) as payload:
-            if set(payload.files) != PAYLOAD_KEYS:
-                raise PreparedPlanError("Prepared feature payload keys are incomplete or unknown.")
-            raw = {k: np.asarray(payload[k]) for k in PAYLOAD_KEYS}
+        with np.load(Path(path), allow_pickle=False) as archive:
+            stored = set(archive.files)
+            if stored != PAYLOAD_KEYS:
+                problem = ", ".join(sorted(stored ^ PAYLOAD_KEYS))
+                raise PreparedPlanError(f"Prepared payload entries differ from the format (missing or unknown: {problem}).")
+            raw = {name: np.asarray(archive[name]) for name, _ in SCHEMA}
     except PreparedPlanError:
         raise
-    except (OSError, ValueError, KeyError) as error:
-        raise PreparedPlanError(f"Prepared feature payload is invalid: {error}") from error
-    mats = [raw["x_train"], raw["x_dev"], raw["x_test"]]
-    if any(str(m.dtype) != feature_dtype for m in mats):
-        raise PreparedPlanError("Prepared feature payload dtype differs from the plan.")
-    if any(m.ndim != 2 for m in mats):
-        raise PreparedPlanError("Prepared feature matrices must all be two-dimensional.")
-    combined = (int(sum(m.shape[0] for m in mats)), int(mats[0].shape[1]))
-    if len({m.shape[1] for m in mats}) != 1 or (feature_shape is not None and combined != tuple(feature_shape)):
-        raise PreparedPlanError("Prepared feature matrices differ from the planned shape.")
-    x_train, x_dev, x_test = (np.asarray(m, dtype=np.float64) for m in mats)
-    if not all(np.all(np.isfinite(m)) for m in (x_train, x_dev, x_test)):
-        raise PreparedPlanError("Prepared feature matrices contain non-finite values.")
-    labels = [raw["y_train"], raw["y_dev"], raw["y_test"]]
-    if any(v.ndim != 1 for v in labels):
-        raise PreparedPlanError("Prepared labels must be one-dimensional arrays.")
-    y_train, y_dev, y_test = ([str(item) for item in v] for v in labels)
-    if any(not label.strip() for label in (*y_train, *y_dev, *y_test)):
-        raise PreparedPlanError("Prepared labels must be non-empty strings.")
-    if x_train.shape[0] != len(y_train) or x_dev.shape[0] != len(y_dev) or x_test.shape[0] != len(y_test):
-        raise PreparedPlanError("Prepared feature/label row counts do not match.")
-    if raw["metadata_json"].ndim != 0:
-        raise PreparedPlanError("Prepared feature metadata payload must be scalar JSON.")
-    try:
-        parsed = json.loads(str(raw["metadata_json"].item()))
-    except json.JSONDecodeError as error:
-        raise PreparedPlanError("Prepared feature metadata is invalid JSON.") from error
-    if not isinstance(parsed, dict):
-        raise PreparedPlanError("Prepared feature metadata must be a JSON object.")
-    return PreparedFeaturePayload(x_train, x_dev, x_test, y_train, y_dev, y_test, parsed)
+    except Exception as error:   # unreadable zip, object arrays refused by allow_pickle=False, I/O errors
+        raise PreparedPlanError(f"Prepared payload {path} cannot be read: {error}") from error
+
+    decoded: dict[str, object] = {}
+    for name, kind in SCHEMA:
+        if kind == "matrix":
+            decoded[name] = _decode_matrix(name, raw[name], feature_dtype)
+        elif kind == "labels":
+            decoded[name] = _decode_labels(name, raw[name])
+        else:
+            decoded["metadata"] = _decode_json(name, raw[name])
+    widths = {decoded[f"x_{p}"].shape[1] for p in PARTITIONS}
+    rows = sum(decoded[f"x_{p}"].shape[0] for p in PARTITIONS)
+    if len(widths) != 1:
+        raise PreparedPlanError(f"Prepared feature matrices differ in width ({sorted(widths)}): not the planned shape.")
+    if feature_shape is not None and (rows, widths.copy().pop()) != tuple(int(v) for v in feature_shape):
+        raise PreparedPlanError(
+            f"Prepared feature matrices hold {rows} x {widths.copy().pop()} values, the planned shape is "
+            f"{tuple(feature_shape)}.")
+    for p in PARTITIONS:
+        if decoded[f"x_{p}"].shape[0] != len(decoded[f"y_{p}"]):
+            raise PreparedPlanError(
+                f"Prepared payload partition {p}: {decoded[f'x_{p}'].shape[0]} feature rows but "
+                f"{len(decoded[f'y_{p}'])} labels.")
+    return PreparedFeaturePayload(**decoded)

@@ -10,6 +10,7 @@ package in.  Plain picklable dataclasses: no GPU state lives here.
 
 from __future__ import annotations
 
+import os
 from collections.abc import Sequence
 from dataclasses import dataclass
 from typing import Protocol, runtime_checkable
@@ -49,6 +50,45 @@ class FeatureFlags:
 
 #: the 187-dim configuration this package accelerates
 FAST_PATH_FLAGS = FeatureFlags(tonnetz=False)
+
+#: environment opt-in that makes ``feature_flags=None`` / ``settings=None`` mean the 187-dim flags
+DEFAULT_FLAGS_ENV = "SERHIP_DEFAULT_FLAGS"
+
+TONNETZ_MESSAGE = (
+    "tonnetz features (HPSS + constant-Q chroma, 6 of the reference's default 193 dims) are outside the "
+    "accelerated path: pass FeatureFlags(tonnetz=False) (187 dims) explicitly, or set "
+    f"{DEFAULT_FLAGS_ENV}=fast187 to make that the meaning of feature_flags=None / settings=None"
+)
+
+
+def default_feature_flags() -> FeatureFlags:
+    """What ``feature_flags=None`` means.  The reference's default is ``FeatureFlags()`` with tonnetz on
+    (193 dims; dsp.py:92, repr/handcrafted.py:38, config/schema.py:219-227), and so is this package's:
+    extraction then raises ``NotImplementedError`` naming the way out, instead of silently returning 187
+    values to a caller whose artifact expects 193.  ``SERHIP_DEFAULT_FLAGS=fast187`` is the one explicit
+    opt-in to the accelerated 187-dim configuration as the default."""
+    choice = os.environ.get(DEFAULT_FLAGS_ENV, "").strip().lower()
+    if choice == "fast187":
+        return FAST_PATH_FLAGS
+    if choice not in ("", "reference", "193"):
+        raise ValueError(f"{DEFAULT_FLAGS_ENV} must be 'fast187' or 'reference', not {choice!r}")
+    return FeatureFlags()
+
+
+def coerce_feature_flags(flags) -> FeatureFlags:
+    """``None`` -> :func:`default_feature_flags`; any object with the five boolean attributes (the
+    reference's own ``FeatureFlags`` dataclass qualifies) -> this package's ``FeatureFlags``."""
+    if flags is None:
+        return default_feature_flags()
+    if isinstance(flags, FeatureFlags):
+        return flags
+    return FeatureFlags(*(bool(getattr(flags, name)) for name, _ in BLOCK_WIDTHS))
+
+
+def require_accelerated(flags: FeatureFlags) -> None:
+    """Raise the loud tonnetz error before any work is done."""
+    if flags.tonnetz:
+        raise NotImplementedError(TONNETZ_MESSAGE)
 
 
 @dataclass(frozen=True)

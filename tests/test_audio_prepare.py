@@ -54,6 +54,27 @@ def test_read_raw_clip_headers_and_segments(tmp_path):
         read_raw_clip(str(p), start_seconds=-1.0)
 
 
+def test_host_prepare_follows_the_librosa_load_order():
+    """Host ``prepare_audio_buffer`` == the oracle's restatement of librosa.load's mix-down followed by
+    ``_prepare_audio_buffer``: 1..9 channels (numpy's pairwise order from 8 on), non-finite samples in one
+    channel, the reference's own known answer (tests/suites/unit/utils/test_audio_utils.py:14-27)."""
+    from oracle import ser_fast_path as ofp
+    from ser_amd.audio_io import prepare_audio_buffer
+
+    rng = np.random.default_rng(3)
+    for ch in range(1, 10):
+        x = rng.standard_normal((257, ch)).astype(np.float32)
+        if ch > 1:
+            x[5, 1] = np.nan
+            x[9, 0] = np.inf
+        arg = x if ch > 1 else x[:, 0]
+        np.testing.assert_array_equal(prepare_audio_buffer(arg), ofp.read_audio_prepared(arg))
+    two = np.array([[0.5, np.nan], [0.25, 0.75], [np.inf, -np.inf]], dtype=np.float32)
+    np.testing.assert_array_equal(prepare_audio_buffer(two), np.array([0.0, 1.0, 0.0], dtype=np.float32))
+    np.testing.assert_array_equal(prepare_audio_buffer(np.array([[0.2, 0.0], [0.4, 0.0]], np.float32)),
+                                  np.array([0.5, 1.0], np.float32))
+
+
 @pytest.mark.gpu
 def test_prepare_audio_bit_exact_vs_numpy():
     """PCM16 and float32, 1..9 channels, NaN/inf, an all-zero clip: identical bits to the oracle."""
@@ -78,21 +99,26 @@ def test_prepare_audio_bit_exact_vs_numpy():
     got = audio.cpu().numpy()
     for c, o, n in zip(clips, out_off, frames):
         raw = c.astype(np.float32) / np.float32(32768.0)
-        want = ofp.prepare_audio_buffer(raw if c.shape[1] > 1 else raw[:, 0])
+        want = ofp.read_audio_prepared(raw if c.shape[1] > 1 else raw[:, 0])
         np.testing.assert_array_equal(got[o : o + n], want)
-    # --- float32 with non-finite samples
+    # --- float32 with non-finite samples: the reference mixes down first (librosa.load) and scrubs the mono
+    # signal, so a NaN / inf in ONE channel zeroes the frame (f[1] frame 5, f[3] frames 7 and 9)
     f = [rng.standard_normal((n, c)).astype(np.float32) * np.float32(3.0) for n, c in ((5000, 1), (2049, 2), (100, 5))]
     f[0][[3, 77, 4000], 0] = [np.nan, np.inf, -np.inf]
     f[1][5, 1] = np.nan
     f[2][50, :] = np.inf
+    f.append(rng.standard_normal((64, 2)).astype(np.float32))
+    f[3][7] = [np.inf, 0.25]
+    f[3][9] = [np.inf, -np.inf]
     raw = np.concatenate([x.reshape(-1) for x in f])
     offs = np.cumsum([0] + [x.size * 4 for x in f[:-1]])
     audio, out_off, frames = eng.prepare_audio(raw, "f32", offs, [x.shape[0] for x in f], [x.shape[1] for x in f])
     got = audio.cpu().numpy()
     for x, o, n in zip(f, out_off, frames):
-        want = ofp.prepare_audio_buffer(x if x.shape[1] > 1 else x[:, 0])
+        want = ofp.read_audio_prepared(x if x.shape[1] > 1 else x[:, 0])
         np.testing.assert_array_equal(got[o : o + n], want)
         assert np.abs(got[o : o + n]).max() == 1.0
+    assert got[out_off[1] + 5] == 0.0 and got[out_off[3] + 7] == 0.0 and got[out_off[3] + 9] == 0.0
     # --- argument errors come back as SerhipError, nothing is launched
     from ser_amd._native import SerhipError
 

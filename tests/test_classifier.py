@@ -24,54 +24,66 @@ class _PredictOnlyModel:
         return np.asarray(self._labels[: len(matrix)])
 
 
-def _frames(n, dim=3):
-    from ser_amd import FeatureFrame
+def _seq(n, dim=3, ends=None):
+    from ser_amd import EncodedSequence
 
-    return [FeatureFrame(start_seconds=float(i), end_seconds=float(i + 3),
-                         features=np.full(dim, 0.1 * i, dtype=np.float64)) for i in range(n)]
+    starts = np.arange(n, dtype=np.float64)
+    return EncodedSequence(np.full((n, dim), 0.1, np.float32), starts,
+                           np.asarray(ends, np.float64) if ends is not None else starts + 3.0, "handcrafted")
 
 
-def test_detailed_prediction_contracts():
-    from ser_amd.fast_inference import (
-        FramePrediction,
-        aggregate_probabilities,
-        predict_emotions_detailed_with_model,
-        segment_predictions,
-    )
+def test_label_run_merge_known_answers():
+    """Segment-merge semantics pinned by the reference's known answers
+    (tests/suites/unit/runtime/test_timestamp_semantics.py:32-110)."""
+    from ser_amd import classify_sequence, merge_label_runs
 
-    # feature-size contract and its message (test_predict_emotions_detailed_rejects_feature_size_mismatch)
-    with pytest.raises(ValueError, match="Feature vector size mismatch for loaded model. Expected 2, got \\[3\\]."):
-        predict_emotions_detailed_with_model("sample.wav", model=_PredictOnlyModel(["neutral"]),
-                                             expected_feature_size=2, output_schema_version="v1",
-                                             extract_feature_frames_fn=lambda _p: _frames(1), logger=LOG)
-    # no frames -> empty result
-    empty = predict_emotions_detailed_with_model("x.wav", model=_PredictOnlyModel([]), expected_feature_size=None,
-                                                 output_schema_version="v1",
-                                                 extract_feature_frames_fn=lambda _p: [], logger=LOG)
-    assert empty.segments == [] and empty.frames == [] and empty.schema_version == "v1"
-    # a model without predict_proba: confidence 1.0, probabilities None; adjacent equal labels merge
-    res = predict_emotions_detailed_with_model(
-        "x.wav", model=_PredictOnlyModel(["calm", "calm", "angry", "calm"]), expected_feature_size=3,
-        output_schema_version="v2", extract_feature_frames_fn=lambda _p: _frames(4), logger=LOG)
-    assert [f.emotion for f in res.frames] == ["calm", "calm", "angry", "calm"]
-    assert all(f.confidence == 1.0 and f.probabilities is None for f in res.frames)
-    assert [(s.emotion, s.start_seconds, s.end_seconds) for s in res.segments] == [
-        ("calm", 0.0, 4.0), ("angry", 2.0, 5.0), ("calm", 3.0, 6.0)]
-    # prediction count mismatch
+    # frames (0,2,angry), (1,3,happy), (2,4.4,happy) -> angry 0-2, happy 1-4.4
+    runs = merge_label_runs([0, 1, 1], [0.0, 1.0, 2.0], [2.0, 3.0, 4.4])
+    assert runs.as_records(["angry", "happy"]) == [
+        {"emotion": "angry", "start_seconds": 0.0, "end_seconds": 2.0, "confidence": 1.0, "probabilities": None},
+        {"emotion": "happy", "start_seconds": 1.0, "end_seconds": 4.4, "confidence": 1.0, "probabilities": None}]
+    assert runs.first.tolist() == [0, 1] and runs.last.tolist() == [0, 2]
+    # length mismatch -> RuntimeError "Frame/prediction length mismatch"
     with pytest.raises(RuntimeError, match="Frame/prediction length mismatch"):
-        predict_emotions_detailed_with_model("x.wav", model=_PredictOnlyModel(["calm"]), expected_feature_size=None,
-                                             output_schema_version="v1",
-                                             extract_feature_frames_fn=lambda _p: _frames(2), logger=LOG)
-    # probability aggregation: mean per label, None if any frame lacks a map or the label sets differ
-    assert aggregate_probabilities([{"a": 0.2, "b": 0.8}, {"a": 0.4, "b": 0.6}]) == pytest.approx({"a": 0.3, "b": 0.7})
-    assert aggregate_probabilities([{"a": 1.0}, None]) is None
-    assert aggregate_probabilities([{"a": 1.0}, {"b": 1.0}]) is None
-    assert aggregate_probabilities([]) is None
-    seg = segment_predictions([FramePrediction(0.0, 1.0, "a", 0.5, {"a": 0.5, "b": 0.5}),
-                               FramePrediction(1.0, 2.0, "a", 0.7, {"a": 0.7, "b": 0.3})])
-    assert len(seg) == 1 and seg[0].confidence == pytest.approx(0.6)
-    assert seg[0].probabilities == pytest.approx({"a": 0.6, "b": 0.4})
-    assert segment_predictions([]) == []
+        merge_label_runs([0, 1], [0.0], [1.0])
+    # a label that comes back is a new segment; confidence and probabilities are per-run means
+    proba = np.asarray([[0.5, 0.5], [0.7, 0.3], [0.2, 0.8], [0.9, 0.1]])
+    runs = merge_label_runs([0, 0, 1, 0], [0, 1, 2, 3], [3, 4, 5, 6], probabilities=proba)
+    assert runs.label_index.tolist() == [0, 1, 0]
+    assert runs.start_seconds.tolist() == [0.0, 2.0, 3.0] and runs.end_seconds.tolist() == [4.0, 5.0, 6.0]
+    np.testing.assert_allclose(runs.confidence, [0.6, 0.8, 0.9])
+    np.testing.assert_allclose(runs.probabilities, [[0.6, 0.4], [0.2, 0.8], [0.9, 0.1]])
+    empty = merge_label_runs([], [], [])
+    assert empty.label_index.size == 0 and empty.as_records([]) == []
+    # a model without predict_proba: confidence 1.0, no probabilities; adjacent equal labels merge
+    classes, labels, p, runs = classify_sequence(_PredictOnlyModel(["calm", "calm", "angry", "calm"]), _seq(4))
+    assert p is None and [classes[i] for i in labels] == ["calm", "calm", "angry", "calm"]
+    assert [(r["emotion"], r["start_seconds"], r["end_seconds"], r["confidence"]) for r in runs.as_records(classes)] == [
+        ("calm", 0.0, 4.0, 1.0), ("angry", 2.0, 5.0, 1.0), ("calm", 3.0, 6.0, 1.0)]
+    with pytest.raises(RuntimeError, match="Frame/prediction length mismatch"):
+        classify_sequence(_PredictOnlyModel(["calm"]), _seq(2))
+    # 3 600 windows of an hour in one pass
+    rng = np.random.default_rng(0)
+    lab = rng.integers(0, 3, size=3600)
+    runs = merge_label_runs(lab, np.arange(3600.0), np.minimum(np.arange(3600.0) + 3, 3600.0))
+    want_first = [0] + [i for i in range(1, 3600) if lab[i] != lab[i - 1]]
+    assert runs.first.tolist() == want_first and int((runs.last - runs.first + 1).sum()) == 3600
+
+
+def _reference_style_inference(frames, model):
+    """What the reference's fast_path.py does with the injected pieces (frames -> model.predict /
+    predict_proba -> merge equal neighbours), written down only as far as this test needs it."""
+    matrix = np.asarray([f.features for f in frames], dtype=np.float64)
+    labels = [str(v) for v in model.predict(matrix)]
+    proba = np.asarray(model.predict_proba(matrix), dtype=np.float64)
+    segments, i = [], 0
+    while i < len(frames):
+        j = i
+        while j + 1 < len(frames) and labels[j + 1] == labels[i]:
+            j += 1
+        segments.append((labels[i], frames[i].start_seconds, frames[j].end_seconds))
+        i = j + 1
+    return labels, proba, segments
 
 
 def _fit(n_classes, hidden=(300,), activation="relu", scaler=True, seed=0, dim=187, n=400):
@@ -125,14 +137,14 @@ def test_gpu_classifier_matches_sklearn(n_classes, hidden, activation, scaler):
 @pytest.mark.gpu
 def test_end_to_end_file_inference_same_labels(tmp_path):
     """Config-2 style: synthetic RAVDESS clips -> GPU features -> sklearn training -> inference on a
-    longer file through predict_emotions_detailed_with_model with the sklearn model and with the GPU
-    classifier: identical frame labels and segments, probabilities within 1e-10."""
+    longer file with the sklearn model and with the GPU classifier injected where the reference takes its
+    ``model=``: identical frame labels and segments, probabilities within 1e-10."""
     from ser_amd import (
         FeatureFlags,
         GpuEmotionClassifier,
         HandcraftedBackend,
+        classify_sequence,
         extract_feature_frames,
-        predict_emotions_detailed_with_model,
     )
     from ser_amd.audio_io import prepare_audio_buffer
     from ser_amd.feature_extractor import FeatureSettings
@@ -163,16 +175,20 @@ def test_end_to_end_file_inference_same_labels(tmp_path):
     path = tmp_path / "long.wav"
     write_wav_pcm16(path, long_clip, 16000)
     settings = FeatureSettings(feature_flags=flags)
+    frames = extract_feature_frames(str(path), settings=settings)
+    want_labels, want_proba, want_segments = _reference_style_inference(frames, model)
+    got_labels, got_proba, got_segments = _reference_style_inference(frames, gpu)   # the drop-in `model=`
+    assert len(frames) == 6 and got_labels == want_labels and got_segments == want_segments
+    np.testing.assert_allclose(got_proba, want_proba, rtol=0, atol=1e-10)
+    # the array form: embeddings stay on the device between the feature kernels and the MLP
+    backend = HandcraftedBackend(feature_flags=flags)
+    from ser_amd.audio_io import read_audio_file
 
-    def frames_fn(p):
-        return extract_feature_frames(p, settings=settings)
-
-    kw = dict(expected_feature_size=187, output_schema_version="v1", extract_feature_frames_fn=frames_fn, logger=LOG)
-    want = predict_emotions_detailed_with_model(str(path), model=model, **kw)
-    got = predict_emotions_detailed_with_model(str(path), model=gpu, **kw)
-    assert len(want.frames) == 6 and [f.emotion for f in got.frames] == [f.emotion for f in want.frames]
-    assert [(s.emotion, s.start_seconds, s.end_seconds) for s in got.segments] == \
-        [(s.emotion, s.start_seconds, s.end_seconds) for s in want.segments]
-    for a, b in zip(got.frames, want.frames):
-        assert a.confidence == pytest.approx(b.confidence, abs=1e-10)
-        assert a.probabilities == pytest.approx(b.probabilities, abs=1e-10)
+    audio, sr = read_audio_file(str(path))
+    enc = backend.encode_sequence(audio, sr)
+    classes, labels, proba, runs = classify_sequence(gpu, enc)
+    assert [str(classes[i]) for i in labels] == want_labels
+    assert [(r["emotion"], r["start_seconds"], r["end_seconds"]) for r in runs.as_records(classes)] == want_segments
+    np.testing.assert_allclose(proba, want_proba, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(runs.confidence,
+                               [want_proba[a : b + 1].max(axis=1).mean() for a, b in zip(runs.first, runs.last)], atol=1e-10)
