@@ -94,6 +94,30 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
                          const int64_t* seg_offset, const int64_t* seg_len, int64_t n_seg,
                          float* out_dev, float* tuning_dev, void* stream);
 
+/* serhip_fast_features for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists
+ * for code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same
+ * arguments, same kernels and bit-identical results as serhip_fast_features, but every byte of scratch
+ * (descriptors, work units, magnitudes, peaks, partial sums) lives in a file-scope `static __device__`
+ * array of SERHIP_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds from code-object load
+ * until the process ends; its device address is resolved once per context in serhip_create
+ * (hipGetSymbolAddress).  The call itself performs no hipMalloc / hipFree / hipHostMalloc / event
+ * creation and no host heap allocation on the success path (the host plan's buffers were reserved in
+ * serhip_create); per-kernel profiling (serhip_profile_*) does not record these launches.
+ * Limits (SERHIP_E_UNSUPPORTED with a message otherwise): at most SERHIP_NOALLOC_MAX_SEGMENTS segments
+ * and SERHIP_NOALLOC_MAX_FRAME_SLOTS STFT frame slots per call (a segment of >= 2048 samples takes
+ * 1 + len/512 frames rounded up to a multiple of 16: a 3 s window at 16 kHz is 96 slots, so 64 such
+ * windows fit), and the byte total of the planned scratch must fit the array.
+ * All calls on one GPU share that GPU's array, which keeps the previous call's contents (what must start
+ * at zero is cleared by the call): calls through ONE context are ordered by the library like users of
+ * its workspace (same stream: stream order; another stream: a device-side event wait), but calls
+ * through different contexts on the same GPU that overlap in time race. */
+#define SERHIP_NOALLOC_SCRATCH_BYTES (48u << 20)
+#define SERHIP_NOALLOC_MAX_SEGMENTS 256
+#define SERHIP_NOALLOC_MAX_FRAME_SLOTS 6144
+int serhip_fast_features_noalloc(serhip_plan* plan, const float* audio_dev, int64_t n_audio,
+                                 const int64_t* seg_offset, const int64_t* seg_len, int64_t n_seg,
+                                 float* out_dev, float* tuning_dev, void* stream);
+
 /* Segment statistics pooling over contiguous frame ranges [win_lo[i], win_hi[i]):
  *   mode 0: out[i] = [mean | population std] in float64, width 2*D
  *           (mean_std_pool, ser/_internal/pool/stats_pool.py:15-43)

@@ -31,6 +31,10 @@ SIGNATURES: dict[str, tuple] = {
         c_int,
         [c_void_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64), c_int64, c_void_p, c_void_p, c_void_p],
     ),
+    "serhip_fast_features_noalloc": (
+        c_int,
+        [c_void_p, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64), c_int64, c_void_p, c_void_p, c_void_p],
+    ),
     "serhip_pool_windows": (
         c_int,
         [c_void_p, c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), c_int32, c_int, c_void_p, c_void_p],

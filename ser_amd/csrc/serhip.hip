@@ -10,7 +10,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
-#include <queue>
 #include <string>
 #include <utility>
 #include <vector>
@@ -137,6 +136,52 @@ void build_host_tables(int sr, HostTables& h, bool with_chroma) {
 
 }  // namespace
 
+// The scratch of serhip_fast_features_noalloc: device memory that exists from the moment the code object is
+// loaded on a GPU until the process ends -- no hipMalloc at call time.  In host code this name is only a
+// stand-in for the symbol: the device address is resolved once per context (= per device) with
+// hipGetSymbolAddress in serhip_create and every use goes through that pointer (serhip_ctx::na_scratch).
+constexpr size_t kNoallocScratchBytes = SERHIP_NOALLOC_SCRATCH_BYTES;    // 48 MiB per GPU
+constexpr int kNoallocMaxSegments = SERHIP_NOALLOC_MAX_SEGMENTS;        // segments per call
+constexpr int kNoallocMaxFrameSlots = SERHIP_NOALLOC_MAX_FRAME_SLOTS;   // STFT frame slots per call
+constexpr size_t kNoallocStagingBytes = 64 << 10;   // pinned host staging for descriptors + work units
+static __device__ __align__(256) unsigned char g_noalloc_scratch[kNoallocScratchBytes];
+
+namespace {
+
+struct Chunk {
+    int64_t first, count;    // range in the descriptor array
+    int max_frames;
+    bool generic;
+    size_t first_unit = 0, n_units = 0;   // fast chunks: header + units in the work-unit array, unit count
+    unsigned wgs = 0;                     // workgroups of the persistent k_stft_frames
+    int unit_frames = kUnitFramesMax;
+};
+
+// host plan of one serhip_fast_features call.  Lives in the context and is reused call after call, so a
+// steady stream of calls does not allocate on the host either.
+struct CallPlan {
+    std::vector<SegDesc> descs, generic;
+    std::vector<Chunk> chunks;
+    std::vector<WorkUnit> units, plain;
+    std::vector<int> owner, per_wg, fill;
+    std::vector<std::pair<long long, int>> heap;
+    size_t max_chunk_frames = 0, gen_frames_max = 0, gen_mel_max = 0, max_chunk_segs = 0;
+    void reserve(size_t segs, size_t frame_slots, size_t cus) {
+        descs.reserve(segs);
+        generic.reserve(segs);
+        chunks.reserve(8);
+        const size_t max_units = frame_slots / 16 + segs;
+        units.reserve(max_units + cus + 2);
+        plain.reserve(max_units);
+        owner.reserve(max_units);
+        per_wg.reserve(cus + 2);
+        fill.reserve(cus + 2);
+        heap.reserve(cus + 2);
+    }
+};
+
+}  // namespace
+
 struct serhip_ctx {
     int device = 0;
     void* ws = nullptr;          // device workspace (scratch + descriptors)
@@ -157,6 +202,15 @@ struct serhip_ctx {
     std::vector<char> head_copy;                // descriptors + work units last uploaded
     uint64_t head_call = 0, head_alloc = 0;     // ws_calls / ws_allocs at that upload
     hipStream_t head_stream = nullptr;
+    CallPlan call_plan;                         // host plan of the current serhip_fast_features call
+    // serhip_fast_features_noalloc: device address of g_noalloc_scratch on this context's GPU, pinned staging
+    // and events created in serhip_create, a plan whose vectors were reserved there
+    void* na_scratch = nullptr;
+    void* na_staging = nullptr;
+    hipEvent_t na_staging_done = nullptr, na_done = nullptr;
+    bool na_staging_used = false, na_marked = false;
+    hipStream_t na_stream = nullptr;
+    CallPlan na_plan;
     void* whisper_blob[2] = {nullptr, nullptr};   // tables for n_mels 80 / 128
     WhisperTables whisper_tb[2] = {};
     // optional per-kernel timing with HIP events (serhip_profile_*)
@@ -312,8 +366,8 @@ struct LaunchTimer {
     hipStream_t stream;
     hipEvent_t start = nullptr, stop = nullptr;
     int kind;
-    LaunchTimer(serhip_ctx* c, int k, hipStream_t s) : ctx(c), stream(s), kind(k) {
-        if (!ctx->profiling) return;
+    LaunchTimer(serhip_ctx* c, int k, hipStream_t s, bool allowed = true) : ctx(c), stream(s), kind(k) {
+        if (!ctx->profiling || !allowed) return;   // the allocation-free entry point creates no events
         start = take_event(ctx);
         stop = take_event(ctx);
         if (start && stop) (void)hipEventRecord(start, stream);
@@ -324,6 +378,217 @@ struct LaunchTimer {
         ctx->timed.push_back({kind, start, stop});
     }
 };
+
+// ---------------------------------------------------------------------------------------
+// planning of one serhip_fast_features call (host): which kernel each segment takes, where its frames
+// sit in the scratch, the work units of the persistent FFT kernel
+// ---------------------------------------------------------------------------------------
+int plan_segments(serhip_ctx* ctx, const char* who, int64_t n_audio, const int64_t* seg_offset, const int64_t* seg_len,
+                  int64_t n_seg, size_t chunk_cap, CallPlan& cp) {
+    cp.descs.clear();
+    cp.generic.clear();
+    cp.chunks.clear();
+    cp.units.clear();
+    cp.max_chunk_frames = cp.gen_frames_max = cp.gen_mel_max = cp.max_chunk_segs = 0;
+    Chunk cur{0, 0, 0, false};
+    size_t cur_frames = 0;
+    for (int64_t i = 0; i < n_seg; ++i) {
+        const int64_t off = seg_offset[i], len = seg_len[i];
+        if (len < 1 || off < 0 || off > n_audio - len)
+            return fail(SERHIP_E_INVALID, std::string(who) + ": segment " + std::to_string(i) + " [" +
+                                              std::to_string(off) + ", +" + std::to_string(len) +
+                                              ") is empty or outside the audio buffer");
+        if (len > 0x7fffffffLL - 4096) return fail(SERHIP_E_UNSUPPORTED, std::string(who) + ": segment too long");
+        const int64_t np = std::max<int64_t>(len, 512);
+        SegDesc d{};
+        d.offset = off;
+        d.out_row = i;
+        d.len = static_cast<int>(len);
+        if (np >= kNfft) {
+            d.n_fft = kNfft;
+            d.n_stft = d.n_mel = static_cast<int>(1 + np / kHop);
+            const size_t fr = (static_cast<size_t>(d.n_stft) + 15) / 16 * 16;   // segments start on a 16-frame tile
+            if (cur.count > 0 && (cur_frames + fr > chunk_cap || cur.count >= 65535)) {
+                cp.chunks.push_back(cur);
+                cp.max_chunk_frames = std::max(cp.max_chunk_frames, cur_frames);
+                cur = Chunk{static_cast<int64_t>(cp.descs.size()), 0, 0, false};
+                cur_frames = 0;
+            }
+            d.stft_base = d.mel_base = static_cast<int>(cur_frames);
+            cur_frames += fr;
+            cur.count += 1;
+            cur.max_frames = std::max(cur.max_frames, d.n_stft);
+            cp.descs.push_back(d);
+        } else {
+            const int n = static_cast<int>(np);
+            d.n_fft = n;
+            d.n_stft = static_cast<int>(1 + (np + 2 * (n / 2) - n) / (n / 4));
+            d.n_mel = static_cast<int>(1 + (np + 2 * (n / 2) - n) / kHop);
+            cp.generic.push_back(d);
+        }
+    }
+    if (cur.count > 0) {
+        cp.chunks.push_back(cur);
+        cp.max_chunk_frames = std::max(cp.max_chunk_frames, cur_frames);
+    }
+    if (cp.max_chunk_frames > 0x7fffffffull / 2) return fail(SERHIP_E_UNSUPPORTED, std::string(who) + ": chunk too large");
+    // generic segments: own chunks, own scratch region
+    {
+        Chunk g{static_cast<int64_t>(cp.descs.size()), 0, 0, true};
+        size_t gs = 0, gm = 0;
+        for (SegDesc& d : cp.generic) {
+            if (g.count >= 65535 || gs + d.n_stft > 65536) {
+                cp.chunks.push_back(g);
+                cp.gen_frames_max = std::max(cp.gen_frames_max, gs);
+                cp.gen_mel_max = std::max(cp.gen_mel_max, gm);
+                g = Chunk{static_cast<int64_t>(cp.descs.size()), 0, 0, true};
+                gs = gm = 0;
+            }
+            d.stft_base = static_cast<int>(gs);
+            d.mel_base = static_cast<int>(gm);
+            gs += d.n_stft;
+            gm += d.n_mel;
+            g.count += 1;
+            g.max_frames = std::max(g.max_frames, d.n_stft + d.n_mel);
+            cp.descs.push_back(d);
+        }
+        if (g.count > 0) {
+            cp.chunks.push_back(g);
+            cp.gen_frames_max = std::max(cp.gen_frames_max, gs);
+            cp.gen_mel_max = std::max(cp.gen_mel_max, gm);
+        }
+    }
+
+    // ---- work units of k_stft_frames: slices of the fast segments, chunk by chunk.  128 frames per unit
+    // when there is work for every CU; a small call (one recording, a few windows) is cut finer, down to
+    // 16 frames, so that it spreads over the chip instead of queueing on a few workgroups.
+    for (Chunk& c : cp.chunks) {
+        if (c.generic) continue;
+        cp.max_chunk_segs = std::max(cp.max_chunk_segs, static_cast<size_t>(c.count));
+        size_t frames = 0;
+        for (int64_t i = 0; i < c.count; ++i) frames += static_cast<size_t>(cp.descs[static_cast<size_t>(c.first + i)].n_stft);
+        const size_t share = (frames + ctx->cu_count - 1) / static_cast<size_t>(ctx->cu_count);
+        c.unit_frames = static_cast<int>(std::min<size_t>(kUnitFramesMax, std::max<size_t>(16, (share + 15) / 16 * 16)));
+        std::vector<WorkUnit>& plain = cp.plain;
+        plain.clear();
+        for (int64_t i = 0; i < c.count; ++i) {
+            const int n_stft = cp.descs[static_cast<size_t>(c.first + i)].n_stft;
+            for (int t0 = 0; t0 < n_stft; t0 += c.unit_frames) plain.push_back(WorkUnit{static_cast<int>(i), t0});
+        }
+        // one workgroup per CU (the kernel's LDS footprint allows no more), never more than units; every
+        // unit goes, in order, to the workgroup with the fewest frames so far
+        c.n_units = plain.size();
+        c.wgs = static_cast<unsigned>(std::min<size_t>(c.n_units, static_cast<size_t>(ctx->cu_count)));
+        std::vector<int>& owner = cp.owner;
+        std::vector<int>& per_wg = cp.per_wg;
+        owner.assign(plain.size(), 0);
+        per_wg.assign(c.wgs + 1, 0);
+        auto unit_len = [&](const WorkUnit& w) {
+            return std::min(c.unit_frames, cp.descs[static_cast<size_t>(c.first + w.seg)].n_stft - w.t_begin);
+        };
+        bool uniform = true;
+        for (size_t k = 1; k < plain.size() && uniform; ++k) uniform = unit_len(plain[k]) == unit_len(plain[0]);
+        if (uniform) {   // equal units: least-loaded is round robin
+            for (size_t k = 0; k < plain.size(); ++k) {
+                owner[k] = static_cast<int>(k % c.wgs);
+                per_wg[owner[k] + 1] += 1;
+            }
+        } else {
+            typedef std::pair<long long, int> Load;   // frames so far, workgroup: a min-heap
+            std::vector<Load>& q = cp.heap;
+            q.clear();
+            for (unsigned b = 0; b < c.wgs; ++b) q.push_back(Load{0, static_cast<int>(b)});   // already a heap
+            for (size_t k = 0; k < plain.size(); ++k) {
+                std::pop_heap(q.begin(), q.end(), std::greater<Load>());
+                Load& l = q.back();
+                l.first += unit_len(plain[k]);
+                owner[k] = l.second;
+                per_wg[l.second + 1] += 1;
+                std::push_heap(q.begin(), q.end(), std::greater<Load>());
+            }
+        }
+        for (unsigned b = 0; b < c.wgs; ++b) per_wg[b + 1] += per_wg[b];
+        c.first_unit = cp.units.size();
+        for (unsigned b = 0; b <= c.wgs; ++b) cp.units.push_back(WorkUnit{per_wg[b], 0});   // header
+        const size_t list0 = cp.units.size();
+        cp.units.resize(list0 + plain.size());
+        std::vector<int>& fill = cp.fill;
+        fill.assign(per_wg.begin(), per_wg.end() - 1);
+        for (size_t k = 0; k < plain.size(); ++k) cp.units[list0 + static_cast<size_t>(fill[owner[k]]++)] = plain[k];
+    }
+    return SERHIP_OK;
+}
+
+// where the pieces of a planned call sit, relative to the base of its scratch:
+// [descriptors | work units | fast scratch | generic scratch]
+struct Placement {
+    size_t seg_bytes, desc_bytes, head_bytes, total;
+    ScratchLayout lf, lg;
+};
+Placement place_call(const CallPlan& cp, int peak_cap) {
+    Placement p{};
+    p.seg_bytes = align_up(cp.descs.size() * sizeof(SegDesc), 256);
+    p.desc_bytes = p.seg_bytes + align_up(cp.units.size() * sizeof(WorkUnit), 256);
+    p.head_bytes = p.seg_bytes + cp.units.size() * sizeof(WorkUnit);
+    p.lf = scratch_layout(cp.max_chunk_frames, peak_cap, cp.max_chunk_segs);
+    p.lg = scratch_layout(std::max(cp.gen_frames_max, cp.gen_mel_max), kGenericPeakCap, 0);
+    p.total = p.desc_bytes + p.lf.total + p.lg.total;
+    return p;
+}
+
+// the launches of a planned call whose descriptors and units are (being) uploaded to `base`
+int launch_chunks(serhip_plan* plan, const CallPlan& cp, const Placement& pl, char* base, const float* audio_dev,
+                  float* out_dev, float* tuning_dev, hipStream_t stream, bool timed) {
+    serhip_ctx* ctx = plan->ctx;
+    SegDesc* d_descs = reinterpret_cast<SegDesc*>(base);
+    const WorkUnit* d_units = reinterpret_cast<const WorkUnit*>(base + pl.seg_bytes);
+    const Scratch sf = scratch_at(base + pl.desc_bytes, pl.lf, plan->peak_cap);
+    const Scratch sg = scratch_at(base + pl.desc_bytes + pl.lf.total, pl.lg, kGenericPeakCap);
+    const bool want_chroma = (plan->flags & SERHIP_FEAT_CHROMA) != 0;
+    const bool want_proj = (plan->flags & (SERHIP_FEAT_MFCC | SERHIP_FEAT_CHROMA | SERHIP_FEAT_MEL)) != 0;
+    for (const Chunk& c : cp.chunks) {
+        const SegDesc* dd = d_descs + c.first;
+        if (!c.generic) {
+            HIP_TRY(hipMemsetAsync(sf.seg_cmax, 0, static_cast<size_t>(c.count) * sizeof(unsigned), stream));
+            {
+                LaunchTimer lt(ctx, SERHIP_KERNEL_STFT_FRAMES, stream, timed);
+                hipLaunchKernelGGL(k_stft_frames, dim3(c.wgs), dim3(kWaves * 64), 0, stream, audio_dev, dd,
+                                   d_units + c.first_unit, c.unit_frames, plan->tb, sf);
+            }
+            const dim3 segs_grid(static_cast<unsigned>(c.count));
+            if (want_chroma || tuning_dev) {   // tuning estimate per segment (zeros when chroma is off)
+                LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream, timed);
+                hipLaunchKernelGGL(k_segment_finish<1>, segs_grid, dim3(256), 0, stream, dd, plan->tb, sf, out_dev,
+                                   tuning_dev, plan->dim);
+            }
+            if (want_proj) {
+                const int tiles = (c.max_frames + kProjTile - 1) / kProjTile;
+                LaunchTimer lt(ctx, SERHIP_KERNEL_PROJECT_FRAMES, stream, timed);
+                hipLaunchKernelGGL(k_project_frames, dim3((tiles + kProjWaves - 1) / kProjWaves, static_cast<unsigned>(c.count)),
+                                   dim3(kProjWaves * 64), 0,
+                                   stream, dd, plan->tb, sf);
+            }
+            {
+                LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream, timed);
+                hipLaunchKernelGGL(k_segment_finish<2>, segs_grid, dim3(256), 0, stream, dd, plan->tb, sf, out_dev,
+                                   tuning_dev, plan->dim);
+            }
+        } else {
+            const dim3 grid(static_cast<unsigned>(c.max_frames), static_cast<unsigned>(c.count));
+            {
+                LaunchTimer lt(ctx, SERHIP_KERNEL_DFT_FRAMES, stream, timed);
+                hipLaunchKernelGGL(k_dft_frames, grid, dim3(256), 0, stream, audio_dev, dd, plan->tb, sg);
+            }
+            {
+                LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream, timed);
+                hipLaunchKernelGGL(k_segment_finish<0>, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
+                                   plan->tb, sg, out_dev, tuning_dev, plan->dim);
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return SERHIP_OK;
+}
 
 // constant tables of the Whisper front end (16 kHz, n_fft 400), built once per n_mels
 int ensure_whisper_tables(serhip_ctx* ctx, int n_mels) {
@@ -463,6 +728,24 @@ int serhip_create(int device_id, serhip_ctx** out) {
         else
             (void)hipGetLastError();
     }
+    // set-up of the allocation-free entry point, once per context with its device current: the device
+    // address of the static scratch ON THIS GPU (every GPU holds its own copy at its own address)
+    {
+        void* sym = nullptr;
+        hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_noalloc_scratch));
+        if (e == hipSuccess) e = hipHostMalloc(&ctx->na_staging, kNoallocStagingBytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->na_staging_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->na_done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            const std::string msg = std::string("serhip_create: static scratch set-up failed: ") + hipGetErrorString(e);
+            (void)hipGetLastError();
+            serhip_destroy(ctx);
+            return fail(SERHIP_E_HIP, msg);
+        }
+        ctx->na_scratch = sym;
+        ctx->na_plan.reserve(kNoallocMaxSegments, kNoallocMaxFrameSlots + 16 * kNoallocMaxSegments,
+                             static_cast<size_t>(ctx->cu_count));
+    }
     if (const char* env = std::getenv("SERHIP_CHUNK_FRAMES")) {
         const long long v = std::atoll(env);
         if (v > 0) ctx->chunk_frames = static_cast<size_t>(v);
@@ -479,6 +762,9 @@ void serhip_destroy(serhip_ctx* ctx) {
     for (void* b : ctx->whisper_blob)
         if (b) (void)hipFree(b);
     if (ctx->staging) (void)hipHostFree(ctx->staging);
+    if (ctx->na_staging) (void)hipHostFree(ctx->na_staging);
+    if (ctx->na_staging_done) (void)hipEventDestroy(ctx->na_staging_done);
+    if (ctx->na_done) (void)hipEventDestroy(ctx->na_done);
     if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
     if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
     for (const serhip_ctx::Timed& t : ctx->timed) {
@@ -637,177 +923,36 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     HIP_TRY(hipSetDevice(ctx->device));
 
-    // ---- plan the call: classify segments, count frames, cut chunks
-    struct Chunk {
-        int64_t first, count;    // range in the descriptor array
-        int max_frames;
-        bool generic;
-        size_t first_unit = 0, n_units = 0;   // fast chunks: header + units in the work-unit array, unit count
-        unsigned wgs = 0;                     // workgroups of the persistent k_stft_frames
-        int unit_frames = kUnitFramesMax;
-    };
-    std::vector<SegDesc> descs;
-    descs.reserve(static_cast<size_t>(n_seg));
-    std::vector<SegDesc> generic;
-    size_t chunk_cap = ctx->chunk_frames ? ctx->chunk_frames : (static_cast<size_t>(1) << 21);
-    std::vector<Chunk> chunks;
-    Chunk cur{0, 0, 0, false};
-    size_t cur_frames = 0, max_chunk_frames = 0;
-    for (int64_t i = 0; i < n_seg; ++i) {
-        const int64_t off = seg_offset[i], len = seg_len[i];
-        if (len < 1 || off < 0 || off > n_audio - len)
-            return fail(SERHIP_E_INVALID, "serhip_fast_features: segment " + std::to_string(i) + " [" +
-                                              std::to_string(off) + ", +" + std::to_string(len) +
-                                              ") is empty or outside the audio buffer");
-        if (len > 0x7fffffffLL - 4096) return fail(SERHIP_E_UNSUPPORTED, "serhip_fast_features: segment too long");
-        const int64_t np = std::max<int64_t>(len, 512);
-        SegDesc d{};
-        d.offset = off;
-        d.out_row = i;
-        d.len = static_cast<int>(len);
-        if (np >= kNfft) {
-            d.n_fft = kNfft;
-            d.n_stft = d.n_mel = static_cast<int>(1 + np / kHop);
-            const size_t fr = (static_cast<size_t>(d.n_stft) + 15) / 16 * 16;   // segments start on a 16-frame tile
-            if (cur.count > 0 && (cur_frames + fr > chunk_cap || cur.count >= 65535)) {
-                chunks.push_back(cur);
-                max_chunk_frames = std::max(max_chunk_frames, cur_frames);
-                cur = Chunk{static_cast<int64_t>(descs.size()), 0, 0, false};
-                cur_frames = 0;
-            }
-            d.stft_base = d.mel_base = static_cast<int>(cur_frames);
-            cur_frames += fr;
-            cur.count += 1;
-            cur.max_frames = std::max(cur.max_frames, d.n_stft);
-            descs.push_back(d);
-        } else {
-            const int n = static_cast<int>(np);
-            d.n_fft = n;
-            d.n_stft = static_cast<int>(1 + (np + 2 * (n / 2) - n) / (n / 4));
-            d.n_mel = static_cast<int>(1 + (np + 2 * (n / 2) - n) / kHop);
-            generic.push_back(d);
-        }
-    }
-    if (cur.count > 0) {
-        chunks.push_back(cur);
-        max_chunk_frames = std::max(max_chunk_frames, cur_frames);
-    }
-    if (max_chunk_frames > 0x7fffffffull / 2) return fail(SERHIP_E_UNSUPPORTED, "serhip_fast_features: chunk too large");
-    // generic segments: own chunks, own scratch region
-    size_t gen_frames_max = 0, gen_mel_max = 0;
-    {
-        Chunk g{static_cast<int64_t>(descs.size()), 0, 0, true};
-        size_t gs = 0, gm = 0;
-        for (SegDesc& d : generic) {
-            if (g.count >= 65535 || gs + d.n_stft > 65536) {
-                chunks.push_back(g);
-                gen_frames_max = std::max(gen_frames_max, gs);
-                gen_mel_max = std::max(gen_mel_max, gm);
-                g = Chunk{static_cast<int64_t>(descs.size()), 0, 0, true};
-                gs = gm = 0;
-            }
-            d.stft_base = static_cast<int>(gs);
-            d.mel_base = static_cast<int>(gm);
-            gs += d.n_stft;
-            gm += d.n_mel;
-            g.count += 1;
-            g.max_frames = std::max(g.max_frames, d.n_stft + d.n_mel);
-            descs.push_back(d);
-        }
-        if (g.count > 0) {
-            chunks.push_back(g);
-            gen_frames_max = std::max(gen_frames_max, gs);
-            gen_mel_max = std::max(gen_mel_max, gm);
-        }
-    }
-
-    // ---- work units of k_stft_frames: slices of the fast segments, chunk by chunk.  128 frames per unit
-    // when there is work for every CU; a small call (one recording, a few windows) is cut finer, down to
-    // 16 frames, so that it spreads over the chip instead of queueing on a few workgroups.
-    std::vector<WorkUnit> units;
-    for (Chunk& c : chunks) {
-        if (c.generic) continue;
-        size_t frames = 0;
-        for (int64_t i = 0; i < c.count; ++i) frames += static_cast<size_t>(descs[static_cast<size_t>(c.first + i)].n_stft);
-        const size_t share = (frames + ctx->cu_count - 1) / static_cast<size_t>(ctx->cu_count);
-        c.unit_frames = static_cast<int>(std::min<size_t>(kUnitFramesMax, std::max<size_t>(16, (share + 15) / 16 * 16)));
-        std::vector<WorkUnit> plain;
-        for (int64_t i = 0; i < c.count; ++i) {
-            const int n_stft = descs[static_cast<size_t>(c.first + i)].n_stft;
-            for (int t0 = 0; t0 < n_stft; t0 += c.unit_frames) plain.push_back(WorkUnit{static_cast<int>(i), t0});
-        }
-        // one workgroup per CU (the kernel's LDS footprint allows no more), never more than units; every
-        // unit goes, in order, to the workgroup with the fewest frames so far
-        c.n_units = plain.size();
-        c.wgs = static_cast<unsigned>(std::min<size_t>(c.n_units, static_cast<size_t>(ctx->cu_count)));
-        std::vector<int> owner(plain.size());
-        std::vector<int> per_wg(c.wgs + 1, 0);
-        auto unit_len = [&](const WorkUnit& w) {
-            return std::min(c.unit_frames, descs[static_cast<size_t>(c.first + w.seg)].n_stft - w.t_begin);
-        };
-        bool uniform = true;
-        for (size_t k = 1; k < plain.size() && uniform; ++k) uniform = unit_len(plain[k]) == unit_len(plain[0]);
-        if (uniform) {   // equal units: least-loaded is round robin
-            for (size_t k = 0; k < plain.size(); ++k) {
-                owner[k] = static_cast<int>(k % c.wgs);
-                per_wg[owner[k] + 1] += 1;
-            }
-        } else {
-            typedef std::pair<long long, int> Load;   // frames so far, workgroup
-            std::priority_queue<Load, std::vector<Load>, std::greater<Load>> q;
-            for (unsigned b = 0; b < c.wgs; ++b) q.push(Load{0, static_cast<int>(b)});
-            for (size_t k = 0; k < plain.size(); ++k) {
-                Load l = q.top();
-                q.pop();
-                l.first += unit_len(plain[k]);
-                owner[k] = l.second;
-                per_wg[l.second + 1] += 1;
-                q.push(l);
-            }
-        }
-        for (unsigned b = 0; b < c.wgs; ++b) per_wg[b + 1] += per_wg[b];
-        c.first_unit = units.size();
-        for (unsigned b = 0; b <= c.wgs; ++b) units.push_back(WorkUnit{per_wg[b], 0});   // header
-        const size_t list0 = units.size();
-        units.resize(list0 + plain.size());
-        std::vector<int> fill(per_wg.begin(), per_wg.end() - 1);
-        for (size_t k = 0; k < plain.size(); ++k) units[list0 + static_cast<size_t>(fill[owner[k]]++)] = plain[k];
-    }
+    CallPlan& cp = ctx->call_plan;
+    const size_t chunk_cap = ctx->chunk_frames ? ctx->chunk_frames : (static_cast<size_t>(1) << 21);
+    int rc = plan_segments(ctx, "serhip_fast_features", n_audio, seg_offset, seg_len, n_seg, chunk_cap, cp);
+    if (rc != SERHIP_OK) return rc;
+    const Placement pl = place_call(cp, plan->peak_cap);
 
     // ---- workspace: [descriptors | work units | fast scratch | generic scratch]
-    const size_t seg_bytes = align_up(descs.size() * sizeof(SegDesc), 256);
-    const size_t desc_bytes = seg_bytes + align_up(units.size() * sizeof(WorkUnit), 256);
-    size_t max_chunk_segs = 0;
-    for (const Chunk& c : chunks)
-        if (!c.generic) max_chunk_segs = std::max(max_chunk_segs, static_cast<size_t>(c.count));
-    const ScratchLayout lf = scratch_layout(max_chunk_frames, plan->peak_cap, max_chunk_segs);
-    const ScratchLayout lg = scratch_layout(std::max(gen_frames_max, gen_mel_max), kGenericPeakCap, 0);
-    int rc = ensure_workspace(ctx, desc_bytes + lf.total + lg.total);
+    rc = ensure_workspace(ctx, pl.total);
     if (rc != SERHIP_OK) return rc;
     WorkspaceUse use(ctx, stream);
     // descriptors and units travel in one copy: the staging buffer mirrors the head of the workspace
-    const size_t head_bytes = seg_bytes + units.size() * sizeof(WorkUnit);
-    const size_t desc_raw = descs.size() * sizeof(SegDesc), unit_raw = units.size() * sizeof(WorkUnit);
+    const size_t desc_raw = cp.descs.size() * sizeof(SegDesc), unit_raw = cp.units.size() * sizeof(WorkUnit);
     char* ws = static_cast<char*>(ctx->ws);
-    SegDesc* d_descs = reinterpret_cast<SegDesc*>(ws);
-    const WorkUnit* d_units = reinterpret_cast<const WorkUnit*>(ws + seg_bytes);
     // the same plan as the last call, nothing else has used the workspace since, same stream: the head of
     // the workspace is still valid
-    const bool head_hit = ctx->head_copy.size() == head_bytes && ctx->head_call + 1 == ctx->ws_calls &&
+    const bool head_hit = ctx->head_copy.size() == pl.head_bytes && ctx->head_call + 1 == ctx->ws_calls &&
                           ctx->head_alloc == ctx->ws_allocs && ctx->head_stream == stream &&
-                          std::memcmp(ctx->head_copy.data(), descs.data(), desc_raw) == 0 &&
-                          (unit_raw == 0 || std::memcmp(ctx->head_copy.data() + seg_bytes, units.data(), unit_raw) == 0);
+                          std::memcmp(ctx->head_copy.data(), cp.descs.data(), desc_raw) == 0 &&
+                          (unit_raw == 0 || std::memcmp(ctx->head_copy.data() + pl.seg_bytes, cp.units.data(), unit_raw) == 0);
     if (!head_hit) {
-        ctx->head_copy.assign(head_bytes, 0);
-        std::memcpy(ctx->head_copy.data(), descs.data(), desc_raw);
-        if (unit_raw) std::memcpy(ctx->head_copy.data() + seg_bytes, units.data(), unit_raw);
-        rc = ensure_staging(ctx, head_bytes);
+        ctx->head_copy.assign(pl.head_bytes, 0);
+        std::memcpy(ctx->head_copy.data(), cp.descs.data(), desc_raw);
+        if (unit_raw) std::memcpy(ctx->head_copy.data() + pl.seg_bytes, cp.units.data(), unit_raw);
+        rc = ensure_staging(ctx, pl.head_bytes);
         if (rc != SERHIP_OK) {
             ctx->head_copy.clear();
             return rc;
         }
-        std::memcpy(ctx->staging, ctx->head_copy.data(), head_bytes);
-        hipError_t e = hipMemcpyAsync(ws, ctx->staging, head_bytes, hipMemcpyHostToDevice, stream);
+        std::memcpy(ctx->staging, ctx->head_copy.data(), pl.head_bytes);
+        hipError_t e = hipMemcpyAsync(ws, ctx->staging, pl.head_bytes, hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipEventRecord(ctx->staging_done, stream);
         if (e != hipSuccess) {
             ctx->head_copy.clear();
@@ -817,54 +962,70 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
         ctx->head_stream = stream;
     }
     ctx->head_call = ctx->ws_calls;
-    const Scratch sf = scratch_at(ws + desc_bytes, lf, plan->peak_cap);
-    const Scratch sg = scratch_at(ws + desc_bytes + lf.total, lg, kGenericPeakCap);
+    return launch_chunks(plan, cp, pl, ws, audio_dev, out_dev, tuning_dev, stream, true);
+}
 
-    // ---- launches
-    const bool want_chroma = (plan->flags & SERHIP_FEAT_CHROMA) != 0;
-    const bool want_proj = (plan->flags & (SERHIP_FEAT_MFCC | SERHIP_FEAT_CHROMA | SERHIP_FEAT_MEL)) != 0;
-    for (const Chunk& c : chunks) {
-        const SegDesc* dd = d_descs + c.first;
-        if (!c.generic) {
-            HIP_TRY(hipMemsetAsync(sf.seg_cmax, 0, static_cast<size_t>(c.count) * sizeof(unsigned), stream));
-            {
-                LaunchTimer lt(ctx, SERHIP_KERNEL_STFT_FRAMES, stream);
-                hipLaunchKernelGGL(k_stft_frames, dim3(c.wgs), dim3(kWaves * 64), 0, stream, audio_dev, dd,
-                                   d_units + c.first_unit, c.unit_frames, plan->tb, sf);
-            }
-            const dim3 segs_grid(static_cast<unsigned>(c.count));
-            if (want_chroma || tuning_dev) {   // tuning estimate per segment (zeros when chroma is off)
-                LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream);
-                hipLaunchKernelGGL(k_segment_finish<1>, segs_grid, dim3(256), 0, stream, dd, plan->tb, sf, out_dev,
-                                   tuning_dev, plan->dim);
-            }
-            if (want_proj) {
-                const int tiles = (c.max_frames + kProjTile - 1) / kProjTile;
-                LaunchTimer lt(ctx, SERHIP_KERNEL_PROJECT_FRAMES, stream);
-                hipLaunchKernelGGL(k_project_frames, dim3((tiles + kProjWaves - 1) / kProjWaves, static_cast<unsigned>(c.count)),
-                                   dim3(kProjWaves * 64), 0,
-                                   stream, dd, plan->tb, sf);
-            }
-            {
-                LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream);
-                hipLaunchKernelGGL(k_segment_finish<2>, segs_grid, dim3(256), 0, stream, dd, plan->tb, sf, out_dev,
-                                   tuning_dev, plan->dim);
-            }
-        } else {
-            const dim3 grid(static_cast<unsigned>(c.max_frames), static_cast<unsigned>(c.count));
-            {
-                LaunchTimer lt(ctx, SERHIP_KERNEL_DFT_FRAMES, stream);
-                hipLaunchKernelGGL(k_dft_frames, grid, dim3(256), 0, stream, audio_dev, dd, plan->tb, sg);
-            }
-            {
-                LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream);
-                hipLaunchKernelGGL(k_segment_finish<0>, dim3(static_cast<unsigned>(c.count)), dim3(256), 0, stream, dd,
-                                   plan->tb, sg, out_dev, tuning_dev, plan->dim);
-            }
+int serhip_fast_features_noalloc(serhip_plan* plan, const float* audio_dev, int64_t n_audio, const int64_t* seg_offset,
+                                 const int64_t* seg_len, int64_t n_seg, float* out_dev, float* tuning_dev,
+                                 void* stream_v) {
+    if (!plan) return fail(SERHIP_E_INVALID, "serhip_fast_features_noalloc: plan is NULL");
+    if (n_seg < 0) return fail(SERHIP_E_INVALID, "serhip_fast_features_noalloc: n_seg < 0");
+    if (n_seg == 0) return SERHIP_OK;
+    if (plan->dim == 0) return SERHIP_OK;
+    if (!audio_dev || !seg_offset || !seg_len || !out_dev)
+        return fail(SERHIP_E_INVALID, "serhip_fast_features_noalloc: NULL buffer");
+    serhip_ctx* ctx = plan->ctx;
+    if (!ctx->na_scratch || !ctx->na_staging)
+        return fail(SERHIP_E_HIP, "serhip_fast_features_noalloc: the static scratch was not resolved at serhip_create");
+    if (n_seg > kNoallocMaxSegments)
+        return fail(SERHIP_E_UNSUPPORTED, "serhip_fast_features_noalloc: " + std::to_string(n_seg) +
+                                              " segments exceed the limit of " + std::to_string(kNoallocMaxSegments) +
+                                              " per call (use serhip_fast_features)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // the vectors of na_plan were reserved at serhip_create for the limits checked here: planning does not
+    // touch the heap.  One chunk of each kind at most (chunk_cap = the frame-slot limit).
+    CallPlan& cp = ctx->na_plan;
+    size_t slots = 0;
+    for (int64_t i = 0; i < n_seg && slots <= static_cast<size_t>(kNoallocMaxFrameSlots); ++i) {
+        const int64_t len = seg_len[i];
+        if (len < 1 || len > 0x7fffffffLL - 4096) continue;   // plan_segments reports it
+        const size_t frames = static_cast<size_t>(serhip_frame_count(len));
+        slots += len >= kNfft ? (frames + 15) / 16 * 16 : frames;
+    }
+    if (slots > static_cast<size_t>(kNoallocMaxFrameSlots))
+        return fail(SERHIP_E_UNSUPPORTED,
+                    "serhip_fast_features_noalloc: the segments need more than " + std::to_string(kNoallocMaxFrameSlots) +
+                        " STFT frame slots (the static scratch holds that many; use serhip_fast_features)");
+    int rc = plan_segments(ctx, "serhip_fast_features_noalloc", n_audio, seg_offset, seg_len, n_seg,
+                           static_cast<size_t>(kNoallocMaxFrameSlots), cp);
+    if (rc != SERHIP_OK) return rc;
+    const Placement pl = place_call(cp, plan->peak_cap);
+    if (pl.total > kNoallocScratchBytes || pl.head_bytes > kNoallocStagingBytes)
+        return fail(SERHIP_E_UNSUPPORTED, "serhip_fast_features_noalloc: the call needs " + std::to_string(pl.total) +
+                                              " bytes of scratch, the static array holds " +
+                                              std::to_string(kNoallocScratchBytes) + " (use serhip_fast_features)");
+    // calls through this context are ordered across streams like users of the hipMalloc'ed workspace
+    if (ctx->na_marked && ctx->na_stream != stream) {
+        if (hipEventRecord(ctx->na_done, ctx->na_stream) != hipSuccess ||
+            hipStreamWaitEvent(stream, ctx->na_done, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
         }
     }
-    HIP_TRY(hipGetLastError());
-    return SERHIP_OK;
+    ctx->na_marked = true;
+    ctx->na_stream = stream;
+    // the previous call's upload has left the pinned staging buffer before it is overwritten
+    if (ctx->na_staging_used) HIP_TRY(hipEventSynchronize(ctx->na_staging_done));
+    char* stage = static_cast<char*>(ctx->na_staging);
+    std::memcpy(stage, cp.descs.data(), cp.descs.size() * sizeof(SegDesc));
+    if (!cp.units.empty()) std::memcpy(stage + pl.seg_bytes, cp.units.data(), cp.units.size() * sizeof(WorkUnit));
+    char* base = static_cast<char*>(ctx->na_scratch);   // the device address of g_noalloc_scratch on this GPU
+    HIP_TRY(hipMemcpyAsync(base, stage, pl.head_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(ctx->na_staging_done, stream));
+    ctx->na_staging_used = true;
+    return launch_chunks(plan, cp, pl, base, audio_dev, out_dev, tuning_dev, stream, false);
 }
 
 int serhip_pool_windows(serhip_ctx* ctx, const float* emb_dev, int32_t n_frames, int32_t dim, const int32_t* win_lo,

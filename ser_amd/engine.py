@@ -82,6 +82,35 @@ class FeatureEngine:
         return c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
     # ------------------------------------------------------------------ hot path
+    def features_into(self, audio_dev, seg_offset, seg_len, sample_rate: int, flags: FeatureFlags, out, *,
+                      tuning=None, plan=None):
+        """Allocation-free form (``serhip_fast_features_noalloc``): ``audio_dev`` and ``out`` (and ``tuning``)
+        are float32 device tensors the caller already owns, ``[n_samples]`` and ``[n_seg, D]``; the library's
+        scratch is a static device array, so nothing is allocated on the GPU by the call.  Bounded: 256
+        segments / 6 144 frame slots per call (``include/serhip.h``).  ``plan`` may be passed to skip the
+        plan lookup (it must have been created before entering a region that forbids allocation)."""
+        require_accelerated(flags)
+        torch = self._torch
+        off, length = _as_i64(seg_offset), _as_i64(seg_len)
+        n_seg = int(off.shape[0])
+        for t, shape in ((audio_dev, None), (out, (n_seg, flags.width()))):
+            if not isinstance(t, torch.Tensor) or t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("features_into takes contiguous float32 tensors on the engine's device")
+            if shape is not None and tuple(t.shape) != shape:
+                raise ValueError(f"out must be {shape}, got {tuple(t.shape)}")
+        with self._torch.cuda.device(self.device), self._lock:
+            if plan is None:
+                plan = self._ctx.plan(int(sample_rate), flags.native_bits())
+            _native.check(
+                self._lib.serhip_fast_features_noalloc(
+                    plan.handle, c_void_p(audio_dev.data_ptr()), int(audio_dev.numel()),
+                    off.ctypes.data_as(POINTER(c_int64)), length.ctypes.data_as(POINTER(c_int64)), n_seg,
+                    c_void_p(out.data_ptr()), c_void_p(tuning.data_ptr()) if tuning is not None else None,
+                    self._stream(),
+                )
+            )
+        return out
+
     def features(self, audio, seg_offset, seg_len, sample_rate: int, flags: FeatureFlags, *,
                  return_tuning: bool = False):
         """Feature matrix ``[n_seg, D]`` (float32, on device) for segments of ``audio``.
