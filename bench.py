@@ -82,6 +82,17 @@ def cpu_baseline(n_clips: int, workers: int) -> dict:
         chunk = max(1, n_clips // (4 * workers))         # reference chunking, data_loader.py:374-379
         done = sum(pool.imap_unordered(_cpu_worker, range(1000, 1000 + n_clips), chunksize=chunk))
         dt = time.perf_counter() - t0
+    # third leg of SURVEY.md 8d: all the host cores this job may use (the box's share is 16 for one GPU;
+    # os.cpu_count() there shows the whole machine)
+    all_cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    all_value = None
+    if all_cores != workers:
+        with ctx.Pool(all_cores, initializer=_one_thread_per_process) as pool:
+            pool.map(_cpu_worker, range(all_cores))
+            t2 = time.perf_counter()
+            done_all = sum(pool.imap_unordered(_cpu_worker, range(20000, 20000 + n_clips),
+                                               chunksize=max(1, n_clips // (4 * all_cores))))
+            all_value = done_all * CLIP_SECONDS / (time.perf_counter() - t2)
     # the same code on ONE core (SURVEY.md 8d asks for both): a twentieth of the sample, this process
     n_single = max(8, n_clips // 20)
     _one_thread_per_process()
@@ -95,6 +106,8 @@ def cpu_baseline(n_clips: int, workers: int) -> dict:
         "unit": "audio-seconds/s",
         "cores": workers,
         "single_core_value": n_single * CLIP_SECONDS / dt_single,
+        "all_cores": all_cores,
+        "all_cores_value": all_value if all_value is not None else done * CLIP_SECONDS / dt,
         "threads_per_process": 1,
         "kind": "port",
         "sample": f"{done} of the config-3 clips (3 s @16 kHz), numpy/scipy restatement of the reference "
@@ -140,8 +153,15 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    nccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not args.rehearse_on_one_gpu and "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ:
+            # RCCL's own account of the transports it connected (read back by rank 0 for the JSON line)
+            nccl_log = f"/tmp/serhip_rccl_{os.getpid()}.log"
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,P2P,SHM,NET"
+            os.environ["NCCL_DEBUG_FILE"] = nccl_log
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -188,24 +208,54 @@ def main() -> None:
         out = step()
     fence()
     engine._ctx.profile_enable(True)
+    # one event per step on the stream the kernels run on (torch's current stream): per-step device times
+    # without a host synchronisation inside the timed region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         out = step()
+        marks[k + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
     engine._ctx.profile_enable(False)
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     k1_ms, k1_n = engine._ctx.profile_read(0)
     k2_ms, k2_n = engine._ctx.profile_read(1)
     k3_ms, k3_n = engine._ctx.profile_read(3)
     assert tuple(out.shape) == (n_total, FEATURE_DIM)
     assert bool(torch.isfinite(out).all())
-    if world > 1:   # every rank holds every rank's rows: rank r's shard differs from rank 0's (different seed)
-        assert not torch.equal(out[:n_local], out[n_local : 2 * n_local])
+    if world > 1:
+        # every rank holds every rank's rows: the `world` shards come from different seeds, so their column
+        # sums differ pairwise; this rank's own rows sit at its own place
+        sums = out.reshape(world, n_local, FEATURE_DIM).double().sum(dim=1).cpu()
+        for a in range(world):
+            for b in range(a + 1, world):
+                assert not torch.equal(sums[a], sums[b]), f"rank {rank}: shards {a} and {b} are identical"
+        mine = engine.features(audio, offsets, lengths, SAMPLE_RATE, flags)
+        assert torch.equal(out[rank * n_local : (rank + 1) * n_local].to(mine.device), mine), f"rank {rank}: own shard misplaced"
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    comm = {"world": world, "backend": None, "transport": None}
+    if world > 1:
+        comm["backend"] = "rccl (torch.distributed 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend()
+        if nccl_log and rank == 0:
+            try:
+                text = Path(nccl_log).read_text(errors="replace")
+                counts = {key: text.count(tag) for key, tag in
+                          (("p2p_ipc", "via P2P/IPC"), ("p2p_direct", "via P2P/direct"), ("p2p_cumem", "via P2P/CUMEM"),
+                           ("shm", "via SHM"), ("net", "via NET"))}
+                ranks_seen = [ln for ln in text.splitlines() if "nranks" in ln][:1]
+                comm["transport"] = {"channel_connections": {k: v for k, v in counts.items() if v},
+                                     "init": ranks_seen[0].split("NCCL INFO")[-1].strip() if ranks_seen else None}
+            except OSError:
+                comm["transport"] = "NCCL_DEBUG log not readable"
+        elif rank == 0:
+            comm["transport"] = "not probed (NCCL_DEBUG set by the caller)" if dist.get_backend() == "nccl" else "tcp (gloo)"
 
     if rank == 0:
         audio_seconds = n_total * CLIP_SECONDS * args.steps
@@ -231,6 +281,10 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "step_ms_min": step_ms[0],
+            "step_ms_median": step_ms[len(step_ms) // 2],
+            "step_ms_max": step_ms[-1],
+            "comm": comm,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -239,6 +293,7 @@ def main() -> None:
             "config": {
                 "workload": "config 3: 100k x 3 s clips @16 kHz sharded by utterance, 12 500 clips per GPU, "
                             "187-dim fast-profile features (mfcc40|chroma12|mel128|contrast7) + all-gather",
+                "descriptor_upload": "skipped after the first step (identical plan replayed: uniform clip batch)",
                 "clips_per_gpu": n_local,
                 "clip_samples": CLIP_SAMPLES,
                 "feature_dim": FEATURE_DIM,
@@ -252,6 +307,8 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this command: TCC FETCH/WRITE_SIZE, "
+                                  "guide's gfx950 corrections), scaled to this run's clips per launch; not re-measured live",
                 "launches_per_step": k1_n / max(1, args.steps),
                 "avg_launch_ms": k1_ms / max(1, k1_n),
                 "finish_kernels_ms_per_step": k2_ms / max(1, args.steps),

@@ -198,6 +198,18 @@ int serhip_mlp_predict(serhip_ctx* ctx, const void* x_dev, int x_is_f64, int64_t
 int serhip_profile_enable(serhip_ctx* ctx, int on);
 int serhip_profile_read(serhip_ctx* ctx, int kind, double* total_ms, int64_t* launches);
 
+/* Diagnostic hook: the tuning estimate alone -- librosa.estimate_tuning's median threshold over the
+ * piptrack peaks followed by librosa.pitch_tuning's 100-bin histogram arg-max, reached from
+ * ser/_internal/utils/dsp.py:115 (chroma_stft) -- computed by the same kernel the hot path uses
+ * (k_segment_finish<1>) from peak lists supplied by the caller instead of by the FFT kernel.  Lets tests
+ * drive the discrete decisions (even-count median, ties, empty sets, more peaks than fit in LDS) with
+ * hand-derived answers.  Synchronous; all pointers are HOST pointers.
+ *   pitch_mag     [sum(frame_counts)][2] float32 (pitch in Hz, magnitude), frame after frame
+ *   frame_counts  [n_frames] peaks per STFT frame
+ *   tuning_out    one float32: the estimate in fractions of a semitone, in [-0.5, 0.5) */
+int serhip_tuning_from_peaks(serhip_plan* plan, const float* pitch_mag, const int32_t* frame_counts,
+                             int32_t n_frames, float* tuning_out);
+
 /* ---- host-only helpers (no GPU touched; used by the CPU test-suite) ---- */
 
 /* Copy one host-built constant table of the fast plan into `out` (f32).

@@ -50,6 +50,7 @@ SIGNATURES: dict[str, tuple] = {
         [c_void_p, c_void_p, c_int, c_int64, c_int32, c_void_p, c_void_p, c_int32, POINTER(c_int32),
          POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p, c_void_p],
     ),
+    "serhip_tuning_from_peaks": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int32), c_int32, POINTER(c_float)]),
     "serhip_profile_enable": (c_int, [c_void_p, c_int]),
     "serhip_profile_read": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
     "serhip_host_table": (c_int64, [c_int, c_int, c_int, POINTER(c_float), c_int64]),

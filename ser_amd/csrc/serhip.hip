@@ -1191,6 +1191,51 @@ int serhip_mlp_predict(serhip_ctx* ctx, const void* x_dev, int x_is_f64, int64_t
     return SERHIP_OK;
 }
 
+int serhip_tuning_from_peaks(serhip_plan* plan, const float* pitch_mag, const int32_t* frame_counts, int32_t n_frames,
+                             float* tuning_out) {
+    if (!plan || !frame_counts || !tuning_out) return fail(SERHIP_E_INVALID, "serhip_tuning_from_peaks: NULL argument");
+    if (n_frames < 1 || n_frames > (1 << 20)) return fail(SERHIP_E_INVALID, "serhip_tuning_from_peaks: n_frames out of range");
+    serhip_ctx* ctx = plan->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int cap = 1;
+    size_t total = 0;
+    for (int t = 0; t < n_frames; ++t) {
+        if (frame_counts[t] < 0 || frame_counts[t] > (1 << 16))
+            return fail(SERHIP_E_INVALID, "serhip_tuning_from_peaks: frame " + std::to_string(t) + " has a bad peak count");
+        cap = std::max(cap, frame_counts[t]);
+        total += static_cast<size_t>(frame_counts[t]);
+    }
+    if (total > 0 && !pitch_mag) return fail(SERHIP_E_INVALID, "serhip_tuning_from_peaks: pitch_mag is NULL");
+    // the scratch rows k_stft_frames would have written: [frame][cap] (pitch, mag) + the counts
+    const size_t frames = (static_cast<size_t>(n_frames) + 15) / 16 * 16;
+    const ScratchLayout lay = scratch_layout(frames, cap, 1);
+    const size_t head = align_up(sizeof(SegDesc), 256);
+    int rc = ensure_workspace(ctx, head + lay.total + 256);
+    if (rc != SERHIP_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());   // a diagnostic call: plainly synchronous
+    ctx->head_copy.clear();            // the head of the workspace is overwritten
+    char* ws = static_cast<char*>(ctx->ws);
+    const Scratch sc = scratch_at(ws + head, lay, cap);
+    SegDesc d{};
+    d.n_fft = kNfft;
+    d.n_stft = d.n_mel = n_frames;
+    std::vector<v2f> rows(static_cast<size_t>(n_frames) * cap, v2f{0.0f, 0.0f});
+    size_t at = 0;
+    for (int t = 0; t < n_frames; ++t)
+        for (int j = 0; j < frame_counts[t]; ++j, ++at) rows[static_cast<size_t>(t) * cap + j] = v2f{pitch_mag[2 * at], pitch_mag[2 * at + 1]};
+    HIP_TRY(hipMemcpy(ws, &d, sizeof(d), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc.peaks, rows.data(), rows.size() * sizeof(v2f), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc.peak_cnt, frame_counts, static_cast<size_t>(n_frames) * sizeof(int), hipMemcpyHostToDevice));
+    float* d_tuning = reinterpret_cast<float*>(ws + head + lay.total);
+    PlanTables tb = plan->tb;
+    tb.flags |= SERHIP_FEAT_CHROMA;    // the estimate runs whatever the plan's flags
+    hipLaunchKernelGGL(k_segment_finish<1>, dim3(1), dim3(256), 0, nullptr, reinterpret_cast<const SegDesc*>(ws), tb, sc,
+                       d_tuning, d_tuning, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(tuning_out, d_tuning, sizeof(float), hipMemcpyDeviceToHost));
+    return SERHIP_OK;
+}
+
 int serhip_profile_enable(serhip_ctx* ctx, int on) {
     if (!ctx) return fail(SERHIP_E_INVALID, "serhip_profile_enable: ctx is NULL");
     ctx->profiling = on != 0;

@@ -154,6 +154,24 @@ class FeatureEngine:
             return out, tuning
         return out
 
+    def tuning_from_peaks(self, frames, sample_rate: int = 16000) -> float:
+        """Diagnostic: the device tuning estimate for per-frame lists of ``(pitch_hz, magnitude)`` peaks
+        (``serhip_tuning_from_peaks``); returns the float32 estimate."""
+        from ctypes import c_float
+
+        counts = np.ascontiguousarray([len(f) for f in frames], dtype=np.int32)
+        flat = np.ascontiguousarray([pm for f in frames for pm in f], dtype=np.float32).reshape(-1, 2)
+        out = c_float(0.0)
+        with self._torch.cuda.device(self.device), self._lock:
+            plan = self._ctx.plan(int(sample_rate), FeatureFlags(tonnetz=False).native_bits())
+            _native.check(
+                self._lib.serhip_tuning_from_peaks(
+                    plan.handle, flat.ctypes.data_as(POINTER(c_float)) if flat.size else None,
+                    counts.ctypes.data_as(POINTER(c_int32)), int(counts.size), ctypes.byref(out),
+                )
+            )
+        return np.float32(out.value)
+
     # ------------------------------------------------------------------ audio preparation
     def prepare_audio(self, raw, sample_format: str, clip_raw_offset, clip_frames, clip_channels):
         """Device form of ``_prepare_audio_buffer`` for a batch of raw clips.

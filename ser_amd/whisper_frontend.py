@@ -5,6 +5,14 @@
 (``ser/_internal/transcript/backends/stable_whisper_mps_compat.py:192-201``):
 16 kHz mono float32 in, ``[n_mels, n_samples // 160]`` float32 out (a leading
 batch axis is kept when the input has one).  Runs ``serhip_whisper_logmel``.
+
+Batch semantics: every clip of a ``[b, n]`` input is processed INDEPENDENTLY -- the ``max - 8`` clamp uses
+the clip's own maximum, which is what Hugging Face's ``WhisperFeatureExtractor`` does per waveform and what
+the reference's call site gets (it passes one clip).  ``whisper.audio.log_mel_spectrogram`` itself, handed a
+batched tensor, would take ``log_spec.max()`` over the WHOLE batch, so there every clip but the loudest
+would be clamped differently; call this function clip by clip if that is what you need to reproduce.
+(``tests/test_gpu_parity.py::test_config5_full_length_clips_vs_hf_extractor`` pins the per-clip form with a
+clip scaled by 1e-3 inside a batch.)
 """
 
 from __future__ import annotations

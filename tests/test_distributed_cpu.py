@@ -74,3 +74,60 @@ def test_all_gather_single_process_passthrough():
     with pytest.raises(ValueError):
         all_gather_rows(x, 5)
     assert np.asarray(x).shape == (4, 3)
+
+
+def _fake_featurize(jobs, *, feature_flags, audio_read_config, workers=8, device_prepare=True):
+    """Stand-in for the GPU featuriser: a row derived from the file name; '*bad*' files fail."""
+    rows = np.full((len(jobs), 4), np.nan, dtype=np.float32)
+    errors = [None] * len(jobs)
+    for i, (path, _s, _d) in enumerate(jobs):
+        if "bad" in path:
+            errors[i] = OSError(f"cannot decode {path}")
+        else:
+            k = int(path.split("_")[1].split(".")[0])
+            rows[i] = [k, 10 * k, 100 * k, 0.5]
+    return rows, errors
+
+
+def _files_worker(rank, world, port, files, result_dir):
+    import torch.distributed as dist
+
+    from ser_amd.data_loader import LoaderSettings, featurize_files
+    from ser_amd.types import FeatureFlags
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    settings = LoaderSettings(feature_flags=FeatureFlags(tonnetz=False))
+    matrix, errors = featurize_files(files, settings=settings, distributed=True, featurize_jobs=_fake_featurize)
+    np.save(os.path.join(result_dir, f"matrix{rank}.npy"), matrix)
+    with open(os.path.join(result_dir, f"errors{rank}.txt"), "w") as f:
+        f.write("\n".join("" if e is None else f"{type(e).__name__}: {e}" for e in errors))
+    dist.destroy_process_group()
+
+
+def test_featurize_files_distributed_gloo_world2(tmp_path):
+    """files -> contiguous shards -> one gather: every rank ends with the single-process matrix (uneven
+    shards: 7 files over 2 ranks); a file that fails on rank 1 is NaN everywhere, reported with its own
+    exception on rank 1 and with a RuntimeError naming rank 1 on rank 0."""
+    import torch.multiprocessing as mp
+
+    from ser_amd.data_loader import LoaderSettings, featurize_files
+    from ser_amd.types import FeatureFlags
+
+    files = [f"/d/clip_{k}.wav" for k in range(5)] + ["/d/bad_5.wav", "/d/clip_6.wav"]
+    single, single_err = featurize_files(files, settings=LoaderSettings(feature_flags=FeatureFlags(tonnetz=False)),
+                                         featurize_jobs=_fake_featurize)
+    assert single.dtype == np.float64 and single.shape == (7, 4) and isinstance(single_err[5], OSError)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_files_worker, args=(2, port, files, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(tmp_path / f"matrix{r}.npy")
+        assert got.dtype == np.float64
+        np.testing.assert_array_equal(got, single)          # NaN row included
+        errs = (tmp_path / f"errors{r}.txt").read_text().split("\n")
+        assert [bool(e) for e in errs] == [False] * 5 + [True, False]
+        assert errs[5] == ("OSError: cannot decode /d/bad_5.wav" if r == 1 else
+                           "RuntimeError: feature extraction of /d/bad_5.wav failed on rank 1")
