@@ -1,7 +1,7 @@
 """Kernel times of the bench workload (12 500 clips x 3 s) without bench.py's result checks: for timing
 ablated builds of the library whose outputs are garbage (SERHIP_LIBRARY=...)."""
 import sys
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from ser_amd import FeatureFlags
 from ser_amd.engine import get_engine

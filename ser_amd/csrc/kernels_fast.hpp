@@ -33,12 +33,35 @@ namespace serhip {
 #ifndef SERHIP_K1_OPAQUE_LANE
 #define SERHIP_K1_OPAQUE_LANE 0
 #endif
+#ifndef SERHIP_K1_PREFETCH
+#define SERHIP_K1_PREFETCH 0
+#endif
+// Frame loads as inline asm with hand-counted waits (see k_stft_frames, "sample loads").
+#ifndef SERHIP_K1_ASMLOAD
+#define SERHIP_K1_ASMLOAD 1
+#endif
 #ifndef SERHIP_K1_OPAQUE_LOAD
 #define SERHIP_K1_OPAQUE_LOAD 1
 #endif
 // k_stft_frames runs ONE workgroup per CU: its waves share the 21 KB of twiddle/window tables in LDS and
 // each owns an 8.5 KB transpose buffer.  16 waves = 4 per SIMD at <= 128 VGPRs fill the 160 KB of LDS;
 // measured on MI355X (12.5k clips): 8 waves 4.2 ms, 12 waves 2.9 ms, 16 waves 2.8 ms.
+// Diagnostic build only (-DSERHIP_K1_STAMPS=1): per-phase shader-cycle sums of every wave, taken with s_memtime
+// at the points where the wave already waits for lgkmcnt(0) (s_memtime shares that counter with LDS), written
+// to Scratch::mel (unused by this kernel) at the end.  Never in a timed or shipped build.
+#ifndef SERHIP_K1_STAMPS
+#define SERHIP_K1_STAMPS 0
+#endif
+#if SERHIP_K1_STAMPS
+#define K1_STAMP(i)                                                              \
+    {                                                                            \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();           \
+        stamp_acc[i] += static_cast<unsigned>(t_now - stamp_prev);               \
+        stamp_prev = t_now;                                                      \
+    }
+#else
+#define K1_STAMP(i)
+#endif
 constexpr int kWaves = SERHIP_K1_WAVES; // waves per workgroup in k_stft_frames
 constexpr int kUnitFramesMax = 128;    // STFT frames per work unit of k_stft_frames (small calls use less)
 constexpr int kBufC = 1088;            // complex slots of one wave's LDS buffer (16 rows x stride 68)
@@ -192,17 +215,43 @@ __device__ __forceinline__ v2f piptrack_peak(float sm, float s0, float sp, int i
     return v2f{static_cast<float>(pitch), __fadd_rn(s0, dskew)};
 }
 
+// One 8-byte sample pair per lane from `sbase + voff + kImm` (bytes), issued as inline asm so that the
+// compiler does not know a load is in flight: it then inserts no s_waitcnt of its own, and the kernel waits
+// with the exact count it needs (k_stft_frames, "sample loads").  global_load_dwordx2 needs 4-byte alignment
+// only (unaligned access mode is on under ROCm), so segments at odd sample offsets take this path too.
+template <int kImm>
+__device__ __forceinline__ void load_pair_async(v2f& dst, const float* sbase, unsigned voff) {
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(kImm));
+}
+// wait until at most kYounger vector-memory operations of this wave are outstanding, and tie the 16 loaded
+// pairs to the wait so that no use of them can be scheduled above it
+template <int kYounger>
+__device__ __forceinline__ void wait_pairs(v2f (&v)[16]) {
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : "n"(kYounger));
+    asm volatile(""
+                 : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+
 // ---------------------------------------------------------------------------------------
 // k_stft_frames
 // ---------------------------------------------------------------------------------------
+// kProj: any of mfcc / chroma / mel is wanted (the magnitudes are stored); kChroma: the piptrack peaks are.
+// Compile-time so that a frame's store count is a constant (see "sample loads").
+template <bool kProj, bool kChroma>
 __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __restrict__ audio,
                                                              const SegDesc* __restrict__ segs,
                                                              const WorkUnit* __restrict__ units,
                                                              int unit_frames, PlanTables tb, Scratch sc) {
-    __shared__ v2f s_twA[16 * 64];
-    __shared__ v2f s_twU[8 * 64];
-    __shared__ v2f s_win[16 * 64];
-    __shared__ v2f s_twB[16 * 4];
+    // The four tables are read from LDS once per frame.  They are kept as PAIRS of consecutive entries
+    // (float4 {t[2j], t[2j+1]} per lane) so that every read is one ds_read_b128: 1 KiB per wave-instruction
+    // in 4 LDS cycles.  The plain [entry][lane] v2f layout made the compiler fuse two 8-byte reads into
+    // ds_read2st64_b64, which moves the same bytes in 8 cycles (MI355X_MICROARCH.md, LDS table).
+    __shared__ __attribute__((aligned(16))) float4 s_twA4[8 * 64];
+    __shared__ __attribute__((aligned(16))) float4 s_twU4[4 * 64];
+    __shared__ __attribute__((aligned(16))) float4 s_win4[8 * 64];
+    __shared__ __attribute__((aligned(16))) float4 s_twB4[8 * 4];
     __shared__ __attribute__((aligned(16))) v2f s_buf[kWaves][kBufC];
     __shared__ int s_next;   // next undrawn position in the concatenation of this workgroup's units
 
@@ -210,12 +259,25 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the unit cursor below is scalar
 
-    for (int i = tid; i < 16 * 64; i += kWaves * 64) {
-        s_twA[i] = tb.twA[i];
-        s_win[i] = tb.win[i];
+    {   // entry e of lane l -> half (e & 1) of pair (e >> 1)
+        v2f* a2 = reinterpret_cast<v2f*>(s_twA4);
+        v2f* w2 = reinterpret_cast<v2f*>(s_win4);
+        v2f* u2 = reinterpret_cast<v2f*>(s_twU4);
+        v2f* b2 = reinterpret_cast<v2f*>(s_twB4);
+        for (int i = tid; i < 16 * 64; i += kWaves * 64) {
+            const int e = i >> 6, l = i & 63, at = ((e >> 1) * 64 + l) * 2 + (e & 1);
+            a2[at] = tb.twA[i];
+            w2[at] = tb.win[i];
+        }
+        for (int i = tid; i < 8 * 64; i += kWaves * 64) {
+            const int e = i >> 6, l = i & 63;
+            u2[((e >> 1) * 64 + l) * 2 + (e & 1)] = tb.twU[i];
+        }
+        if (tid < 64) {
+            const int e = tid >> 2, l = tid & 3;   // twB is [16][4]
+            b2[((e >> 1) * 4 + l) * 2 + (e & 1)] = tb.twB[tid];
+        }
     }
-    for (int i = tid; i < 8 * 64; i += kWaves * 64) s_twU[i] = tb.twU[i];
-    if (tid < 64) s_twB[tid] = tb.twB[tid];
     if (tid == 0) s_next = 0;
     __syncthreads();
 
@@ -227,10 +289,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     const float sg1 = (q & 2) ? -1.0f : 1.0f;
     const float sg2 = (q & 1) ? -1.0f : 1.0f;
     const int j2 = ((q & 1) << 1) | (q >> 1);
-    const int k1b = lane >> 2;
+    // stage-B row of this lane's quad.  Any bijection quad -> row works for the arithmetic; this one makes the
+    // transposed read below conflict-free as ds_read_b128: that instruction serves the lane groups
+    // {quads 0,3,5,6}, {1,2,4,7} (and the same + 8) in one LDS cycle each, a row starts 8 * row banks further
+    // (row stride 68 complex = 136 dwords), and a quad covers 16 banks -- so the rows of a group must be
+    // 2 apart: quads 0,3,5,6 -> rows 0,2,4,6 and quads 1,2,4,7 -> rows 1,3,5,7.
+    const int k1b = (lane >> 2) ^ (((lane >> 3) ^ (lane >> 4)) & 1);
+    // column of this lane in the stage-A rows: within every 8 columns (c = 8j + 4e + q -> 8j + 2q + e) the two
+    // columns 4(2j) + q and 4(2j+1) + q that one stage-B lane needs sit side by side
+    const int colA = (lane & ~7) | ((lane & 3) << 1) | ((lane >> 2) & 1);
     const double sr_d = static_cast<double>(tb.sample_rate);
-    const bool want_chroma = (tb.flags & 2u) != 0;
-    const bool want_proj = (tb.flags & 7u) != 0;   // any of mfcc / chroma / mel needs the magnitudes
+    constexpr bool want_chroma = kChroma;
+    constexpr bool want_proj = kProj;   // any of mfcc / chroma / mel needs the magnitudes
 
     // ---- cursor over this workgroup's units (wave-uniform, scalar registers).  `pos` is this wave's
     // position in the concatenation of the workgroup's units (drawn from s_next, so it only grows),
@@ -294,6 +364,70 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             }
         }
     };
+#if SERHIP_K1_ASMLOAD
+    // ---- sample loads.  The 16 loads of the NEXT frame are issued as soon as the unpack of the frame in hand
+    // has released the transform's registers, i.e. before that frame's stores; they are waited for at the top
+    // of the next transform.  vmcnt counts loads and stores together, in order, and a store's acknowledgement
+    // takes as long as a load from HBM: a compiler-placed wait (vmcnt(0) as soon as a conditional store sits
+    // between load and use) made every frame wait for its predecessor's stores -- ~2 500 of a frame's 15 500
+    // wave-cycles (in-kernel stamps).  Here every frame issues, AFTER its prefetch loads, a fixed number of
+    // stores (finish_frame, "store block"), so `vmcnt(that number)` means: the loads have landed, the stores
+    // may still be in flight.
+    // Every frame takes exactly 16 global_load_dwordx2.  An interior frame reads sbase + 8*lane + 512*n1; a
+    // frame that overlaps the zero padding of librosa.stft(center=True) reads pair-wise clamped addresses and
+    // repairs the values after the wait (fix_padded_frame).
+    auto load_frame_async = [&, lane_outer = lane](int t, v2f (&dst)[16]) {
+        int lane = lane_outer;
+        asm volatile("" : "+v"(lane));
+        const int fs = t * kHop - kNfft / 2;   // < 2^31: the host rejects longer segments
+        const float* seg_audio = audio + sd.offset;
+        if (fs >= 0 && fs + kNfft <= sd.len) {
+            const float* b0 = seg_audio + fs;
+            const float* b1 = b0 + 1024;       // immediate offsets reach 4 KiB
+            const unsigned voff = 8u * static_cast<unsigned>(lane);
+            load_pair_async<0>(dst[0], b0, voff);
+            load_pair_async<512>(dst[1], b0, voff);
+            load_pair_async<1024>(dst[2], b0, voff);
+            load_pair_async<1536>(dst[3], b0, voff);
+            load_pair_async<2048>(dst[4], b0, voff);
+            load_pair_async<2560>(dst[5], b0, voff);
+            load_pair_async<3072>(dst[6], b0, voff);
+            load_pair_async<3584>(dst[7], b0, voff);
+            load_pair_async<0>(dst[8], b1, voff);
+            load_pair_async<512>(dst[9], b1, voff);
+            load_pair_async<1024>(dst[10], b1, voff);
+            load_pair_async<1536>(dst[11], b1, voff);
+            load_pair_async<2048>(dst[12], b1, voff);
+            load_pair_async<2560>(dst[13], b1, voff);
+            load_pair_async<3072>(dst[14], b1, voff);
+            load_pair_async<3584>(dst[15], b1, voff);
+        } else {
+            // pair (s, s+1), s = fs + 128 n1 + 2 lane, read from the clamped pair start sc = clamp(s, 0, len-2)
+            // (always inside the segment: len >= 2048 here), relative to a wave-uniform base inside the segment
+            const int b = min(max(fs, 0), sd.len - kNfft);
+            const float* b0 = seg_audio + b;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int sx = fs + 128 * n1 + 2 * lane;
+                const unsigned voff = 4u * static_cast<unsigned>(min(max(sx, 0), sd.len - 2) - b);
+                load_pair_async<0>(dst[n1], b0, voff);
+            }
+        }
+    };
+    // after the wait: pair n1 holds (x[sc], x[sc+1]); wanted is (x[s], x[s+1]) with zeros outside [0, len)
+    auto fix_padded_frame = [&, lane_outer = lane](int t, v2f (&dst)[16]) {
+        const int lane = lane_outer;
+        const int fs = t * kHop - kNfft / 2;
+        if (fs >= 0 && fs + kNfft <= sd.len) return;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int sx = fs + 128 * n1 + 2 * lane;
+            const bool whole = sx >= 0 && sx <= sd.len - 2;          // then sc == s: both samples as loaded
+            const bool last = sx == sd.len - 1;                      // sc = len - 2: x[s] is the second one
+            dst[n1] = v2f{whole ? dst[n1].x : (last ? dst[n1].y : 0.0f), whole ? dst[n1].y : 0.0f};
+        }
+    };
+#endif
     const v2f rot3 = (q == 3) ? v2f{0.0f, -1.0f} : v2f{1.0f, 0.0f};   // lane 3 of a quad turns by -i
     // bit r: bin lane + 64 r lies in the piptrack range [kmin, kmax] (one VGPR instead of a set of
     // hoisted scalar conditions per stripe, which spilled SGPRs)
@@ -301,23 +435,52 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         if (lane + 64 * r >= tb.kmin && lane + 64 * r <= tb.kmax) in_range |= 1u << r;
+#if SERHIP_K1_STAMPS
+    unsigned stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned stamp_frames = 0;
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_first = stamp_prev;
+#endif
     // one frame, consumed from v (the raw sample pairs loaded by load_frame)
     auto transform_frame = [&](v2f (&v)[16]) {
         // s_win holds HALF the Hann window: the FFT is linear and halving is exact, so the unpack below
         // needs no 0.5 factors
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = v[n1] * s_win[n1 * 64 + lane];
+        for (int n1 = 0; n1 < 16; n1 += 2) {
+            const float4 w = s_win4[(n1 >> 1) * 64 + lane];
+            v[n1] = v[n1] * v2f{w.x, w.y};
+            v[n1 + 1] = v[n1 + 1] * v2f{w.z, w.w};
+        }
+#if SERHIP_K1_STAMPS && !SERHIP_K1_ASMLOAD
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) asm volatile("" : "+v"(v[n1]));
+#endif
+        K1_STAMP(9)
 
         // ---- stage A: 16-pt DFT over n1 (registers), twiddle W_1024^(lane*k1), transpose
         fft16(v);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) v[SERHIP_REV4(k1)] = cmul(v[SERHIP_REV4(k1)], s_twA[k1 * 64 + lane]);
+        for (int k1 = 0; k1 < 16; k1 += 2) {
+            const float4 w = s_twA4[(k1 >> 1) * 64 + lane];
+            if (k1 > 0) v[SERHIP_REV4(k1)] = cmul(v[SERHIP_REV4(k1)], v2f{w.x, w.y});
+            v[SERHIP_REV4(k1 + 1)] = cmul(v[SERHIP_REV4(k1 + 1)], v2f{w.z, w.w});
+        }
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) buf[k1 * 68 + lane] = v[SERHIP_REV4(k1)];
+        for (int k1 = 0; k1 < 16; ++k1) buf[k1 * 68 + colA] = v[SERHIP_REV4(k1)];
         wave_lds_sync();
+        K1_STAMP(1)
+        {
+            const float4* b4 = reinterpret_cast<const float4*>(buf) + k1b * 34 + q;
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) v[m1] = buf[k1b * 68 + 4 * m1 + q];
+            for (int j = 0; j < 8; ++j) {   // columns 4 m1 + q for m1 = 2j, 2j + 1: one 16-byte read
+                const float4 t = b4[4 * j];
+                v[2 * j] = v2f{t.x, t.y};
+                v[2 * j + 1] = v2f{t.z, t.w};
+            }
+        }
         wave_lds_sync();
+        K1_STAMP(2)
 
         // ---- stage B: 16-pt DFT over m1, twiddle W_64^(m2*j1), radix-4 across the quad
         fft16(v);
@@ -327,8 +490,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
 #pragma unroll
         for (int j1 = 0; j1 < 16; j1 += 2) {
             v2f xa = v[SERHIP_REV4(j1)], xb = v[SERHIP_REV4(j1 + 1)];
-            if (j1 > 0) xa = cmul(xa, s_twB[j1 * 4 + q]);
-            xb = cmul(xb, s_twB[(j1 + 1) * 4 + q]);
+            const float4 wb = s_twB4[(j1 >> 1) * 4 + q];
+            if (j1 > 0) xa = cmul(xa, v2f{wb.x, wb.y});
+            xb = cmul(xb, v2f{wb.z, wb.w});
             const v2f pa = v2f{dpp_mov<0x4E>(xa.x), dpp_mov<0x4E>(xa.y)};   // lane ^ 2
             const v2f pb = v2f{dpp_mov<0x4E>(xb.x), dpp_mov<0x4E>(xb.y)};
             const v2f ta = pa + sg1 * xa;
@@ -342,10 +506,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             buf[k1b + 16 * (j1 + 1) + 260 * j2] = qb + sg2 * ub;
         }
         wave_lds_sync();
+        K1_STAMP(3)
     };
     // second half of a frame: Z (in this wave's LDS buffer) -> |X|, stores, peaks.  Needs no registers
     // of the transform, so the next frame's samples are requested before it starts.
-    auto finish_frame = [&, lane_outer = lane](size_t row, int seg) {
+    auto finish_frame = [&, lane_outer = lane](size_t row, int seg, auto&& after_unpack) {
 #if SERHIP_K1_OPAQUE_LANE
         // an opaque copy of the lane id: the addresses derived from it are recomputed per frame instead of
         // being hoisted out of the frame loop into ~40 VGPRs that the transform needs
@@ -357,18 +522,23 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         // ---- real-FFT unpack: bins k = lane + 64r and 1024 - k from Z[k], Z[1024-k]
         float mlo[8], mhi[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int k = lane + 64 * r;
-            const int kk = (1024 - k) & 1023;
-            const v2f za = buf[k + 4 * (r >> 2)];
-            const v2f zb = buf[kk + 4 * (kk >> 8)];
-            const v2f e2 = add_conj(za, zb);           // E  (the window is pre-halved)
-            const v2f o2 = sub_conj_neg_i(za, zb);     // O
-            const v2f t2 = cmul(o2, s_twU[r * 64 + lane]);
-            const v2f xlo = e2 + t2;
-            const v2f xhi = e2 - t2;
-            mlo[r] = __builtin_amdgcn_sqrtf(xlo.x * xlo.x + xlo.y * xlo.y);   // v_sqrt_f32, <= 1 ulp
-            mhi[r] = __builtin_amdgcn_sqrtf(xhi.x * xhi.x + xhi.y * xhi.y);
+        for (int rp = 0; rp < 4; ++rp) {
+            const float4 wu = s_twU4[rp * 64 + lane];   // W_2048^(lane + 64 r) for r = 2 rp, 2 rp + 1
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 2 * rp + h;
+                const int k = lane + 64 * r;
+                const int kk = (1024 - k) & 1023;
+                const v2f za = buf[k + 4 * (r >> 2)];
+                const v2f zb = buf[kk + 4 * (kk >> 8)];
+                const v2f e2 = add_conj(za, zb);           // E  (the window is pre-halved)
+                const v2f o2 = sub_conj_neg_i(za, zb);     // O
+                const v2f t2 = cmul(o2, h ? v2f{wu.z, wu.w} : v2f{wu.x, wu.y});
+                const v2f xlo = e2 + t2;
+                const v2f xhi = e2 - t2;
+                mlo[r] = __builtin_amdgcn_sqrtf(xlo.x * xlo.x + xlo.y * xlo.y);   // v_sqrt_f32, <= 1 ulp
+                mhi[r] = __builtin_amdgcn_sqrtf(xhi.x * xhi.x + xhi.y * xhi.y);
+            }
         }
         float m512 = 0.0f;
         if (lane == 0) {
@@ -376,6 +546,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             m512 = 2.0f * __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);   // Z is half-scaled
         }
         wave_lds_sync();  // every lane has read Z before the buffer is reused
+        K1_STAMP(4)
+        after_unpack();
 
         // column maximum on the bit patterns: magnitudes are non-negative, so unsigned integer order is
         // float order and v_max3_u32 needs none of the NaN canonicalisation fmaxf drags in
@@ -389,7 +561,74 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         }
         if (lane == 0) sM[512] = m512;
         wave_lds_sync();
+        K1_STAMP(5)
 
+#if SERHIP_K1_ASMLOAD
+        // ---- the segment's largest magnitude bounds its mel power from above: k_project_frames uses it to tell
+        // which dB rows can never be clipped by top_db and need not be stored; the frame's own is piptrack's ref
+        if (want_proj || want_chroma) cmax_bits = wave_max_bits(cmax_bits);
+        K1_STAMP(0)
+        // ---- piptrack peaks (bins kmin..kmax), threshold 0.1 * column max.  Pass 1 finds the local
+        // maxima and compacts their bin numbers into LDS; pass 2 gives each lane one peak, so the
+        // double-precision interpolation runs once per 64 peaks instead of once per bin stripe.
+        int base = 0;
+        v2f first_peak = v2f{0.0f, 0.0f};
+        v2f* prow = sc.peaks + row * sc.peak_cap;
+        if (want_chroma) {
+            const float cmax = __uint_as_float(cmax_bits);
+            const float ref = 0.1f * cmax;
+            int* cand = reinterpret_cast<int*>(fbuf + 1032);   // behind sM
+            // librosa thresholds S below ref to 0 before localmax; with s0 > ref that is the same as
+            // comparing the raw neighbours (a neighbour <= ref is < s0 either way)
+            auto scan_stripe = [&](int r, float s0) {
+                const int k = lane + 64 * r;
+                const bool cand_ok = (s0 > ref) & (((in_range >> r) & 1u) != 0u);
+                if (__ballot(cand_ok) == 0ull) return;   // wave-uniform: most stripes hold nothing above ref
+                // both neighbours are read unconditionally and the tests combined without short-circuit
+                // branches: one LDS round trip per stripe instead of two nested ones
+                const float sm = sM[max(k - 1, 0)], sp = sM[k + 1];
+                const bool is_peak = cand_ok & (s0 > sm) & (s0 >= sp);
+                const unsigned long long mask = __ballot(is_peak);
+                if (is_peak) cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+                base += __popcll(mask);
+            };
+#pragma unroll
+            for (int r = 0; r < 8; ++r) scan_stripe(r, mlo[r]);
+            for (int r = 8; 64 * r <= tb.kmax; ++r) scan_stripe(r, sM[lane + 64 * r]);   // sample rates < 16 kHz
+            wave_lds_sync();
+        K1_STAMP(6)
+            // peaks 64, 65, ... of a frame (rare) are stored here, ahead of the store block
+            for (int i = lane + 64; i < base; i += 64) {
+                const int k = cand[i];
+                prow[i] = piptrack_peak<true>(sM[k - 1], sM[k], sM[k + 1], k, sr_d, static_cast<double>(kNfft));
+            }
+            if (lane < base) {
+                const int k = cand[lane];
+                first_peak = piptrack_peak<true>(sM[k - 1], sM[k], sM[k + 1], k, sr_d, static_cast<double>(kNfft));
+            }
+        }
+        // ---- store block: the LAST vector-memory operations of a frame, and always the same number of them
+        // (kStoresChroma + kStoresProj, by the plan's flags), so that the next frame can wait for its samples
+        // with an exact count (see "sample loads").  Lane 0 takes part in every one of them.
+        if (want_chroma) {
+            if (lane < base || lane == 0) prow[lane] = first_peak;   // slot 0 exists (peak_cap >= 8); count 0 says ignore it
+            if (lane == 0) sc.peak_cnt[row] = base;
+        }
+        if (want_proj) {
+            // magnitudes for k_project_frames: a linear copy of sM, float4 chunk (lane + 64u) per lane
+            // (conflict-free ds_read_b128; eight whole 128-byte lines per store instruction); bin 1024 is
+            // stored with three zero pads so the last 16-bin group reads defined values
+            const float4* mp = reinterpret_cast<const float4*>(sM);
+            float4* m4 = reinterpret_cast<float4*>(sc.mags);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m4[mags_tile_index(row, lane + 64 * u)] = mp[lane + 64 * u];
+            if (lane == 0) m4[mags_tile_index(row, 256)] = float4{mhi[0], 0.0f, 0.0f, 0.0f};
+            if (lane == 0) atomicMax(&sc.seg_cmax[seg], cmax_bits);
+        }
+        wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
+        K1_STAMP(7)
+    };
+#else
         // ---- magnitudes for k_project_frames: a linear copy of sM, float4 chunk (lane + 64u) per lane
         // (conflict-free ds_read_b128; eight whole 128-byte lines per store instruction); bin 1024 is
         // stored with three zero pads so the last 16-bin group reads defined values
@@ -410,6 +649,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             cmax_bits = wave_max_bits(cmax_bits);
             if (lane == 0) atomicMax(&sc.seg_cmax[seg], cmax_bits);
         }
+        K1_STAMP(0)
         if (want_chroma) {
             const float cmax = __uint_as_float(cmax_bits);
             const float ref = 0.1f * cmax;
@@ -433,6 +673,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             for (int r = 0; r < 8; ++r) scan_stripe(r, mlo[r]);
             for (int r = 8; 64 * r <= tb.kmax; ++r) scan_stripe(r, sM[lane + 64 * r]);   // sample rates < 16 kHz
             wave_lds_sync();
+        K1_STAMP(6)
             v2f* prow = sc.peaks + row * sc.peak_cap;
             for (int i = lane; i < base; i += 64) {
                 const int k = cand[i];
@@ -441,8 +682,46 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             if (lane == 0) sc.peak_cnt[row] = base;
         }
         wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
+        K1_STAMP(7)
     };
 
+#endif
+#if SERHIP_K1_ASMLOAD
+    // vector-memory operations in the store block of finish_frame
+    constexpr int kStoreBlock = (kChroma ? 2 : 0) + (kProj ? 6 : 0);
+    v2f v[16];
+    bool more = seek();
+    if (more) {
+        load_frame_async(wu.t_begin + (pos - base), v);
+        // the first frame has no predecessor whose store block would follow its loads: stand-ins, so that the
+        // one wait below is right for every frame (the stored value is what the frame will store there anyway
+        // or overwrite: its own peak count slot)
+        if (lane == 0) {
+            volatile int* slot = sc.peak_cnt + static_cast<size_t>(sd.stft_base) + static_cast<size_t>(wu.t_begin + (pos - base));
+#pragma unroll
+            for (int i = 0; i < kStoreBlock; ++i) *slot = 0;   // volatile: kStoreBlock separate store instructions
+        }
+    }
+    while (more) {
+        const int t = wu.t_begin + (pos - base);
+        const size_t row = static_cast<size_t>(sd.stft_base) + static_cast<size_t>(t);
+        const int drawn = draw();
+        const int seg = wu.seg;
+        // the samples of this frame: everything but the store block that followed their loads has to be done
+        wait_pairs<kStoreBlock>(v);
+        fix_padded_frame(t, v);
+        transform_frame(v);
+        finish_frame(row, seg, [&]() {
+            pos = __builtin_amdgcn_readfirstlane(drawn);
+            more = seek();
+            if (more) load_frame_async(wu.t_begin + (pos - base), v);
+        });
+        K1_STAMP(8)
+#if SERHIP_K1_STAMPS
+        ++stamp_frames;
+#endif
+    }
+#else
     // The next frame's samples are requested after this frame's stores.  Requesting them earlier (into
     // the registers the transform has released, ahead of the stores in the vmcnt queue) was measured
     // twice, spill-free, and is 2-3 % slower: the waves do not wait on these loads.
@@ -454,11 +733,34 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         const int drawn = draw();
         const int seg = wu.seg;
         transform_frame(v);
-        finish_frame(row, seg);
+#if SERHIP_K1_PREFETCH
+        // the next frame's samples are requested as soon as the unpack has released the transform's
+        // registers: the stores and the peak search of this frame (a third of its time) cover their latency
+        finish_frame(row, seg, [&]() {
+            pos = __builtin_amdgcn_readfirstlane(drawn);
+            more = seek();
+            if (more) load_frame(wu.t_begin + (pos - base), v);
+        });
+#else
+        finish_frame(row, seg, []() {});
         pos = __builtin_amdgcn_readfirstlane(drawn);
         more = seek();
         if (more) load_frame(wu.t_begin + (pos - base), v);
+#endif
+        K1_STAMP(8)
+#if SERHIP_K1_STAMPS
+        ++stamp_frames;
+#endif
     }
+#endif
+#if SERHIP_K1_STAMPS
+    if (lane == 0) {
+        unsigned* dst = reinterpret_cast<unsigned*>(sc.mel) + (blockIdx.x * kWaves + wave) * 16;
+        for (int i = 0; i < 10; ++i) dst[i] = stamp_acc[i];
+        dst[10] = stamp_frames;
+        dst[11] = static_cast<unsigned>(__builtin_amdgcn_s_memtime() - stamp_first);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -552,9 +552,25 @@ int launch_chunks(serhip_plan* plan, const CallPlan& cp, const Placement& pl, ch
             HIP_TRY(hipMemsetAsync(sf.seg_cmax, 0, static_cast<size_t>(c.count) * sizeof(unsigned), stream));
             {
                 LaunchTimer lt(ctx, SERHIP_KERNEL_STFT_FRAMES, stream, timed);
-                hipLaunchKernelGGL(k_stft_frames, dim3(c.wgs), dim3(kWaves * 64), 0, stream, audio_dev, dd,
+                auto* k1 = want_proj ? (want_chroma ? k_stft_frames<true, true> : k_stft_frames<true, false>)
+                                     : (want_chroma ? k_stft_frames<false, true> : k_stft_frames<false, false>);
+                hipLaunchKernelGGL(k1, dim3(c.wgs), dim3(kWaves * 64), 0, stream, audio_dev, dd,
                                    d_units + c.first_unit, c.unit_frames, plan->tb, sf);
             }
+#if SERHIP_K1_STAMPS
+            {   // diagnostic build: print the per-phase cycle sums the FFT kernel left in the dB-row scratch
+                (void)hipStreamSynchronize(stream);
+                std::vector<unsigned> st(static_cast<size_t>(c.wgs) * kWaves * 16);
+                (void)hipMemcpy(st.data(), sf.mel, st.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+                double sum[12] = {0};
+                for (size_t w = 0; w < static_cast<size_t>(c.wgs) * kWaves; ++w)
+                    for (int i = 0; i < 12; ++i) sum[i] += st[w * 16 + i];
+                std::fprintf(stderr, "k1 stamps: frames/wave %.1f, cycles/frame total %.0f; phases:", sum[10] / (c.wgs * kWaves),
+                             sum[11] / sum[10]);
+                for (int i = 0; i <= 9; ++i) std::fprintf(stderr, " P%d %.0f", i, sum[i] / sum[10]);
+                std::fprintf(stderr, "\n");
+            }
+#endif
             const dim3 segs_grid(static_cast<unsigned>(c.count));
             if (want_chroma || tuning_dev) {   // tuning estimate per segment (zeros when chroma is off)
                 LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream, timed);

@@ -145,3 +145,18 @@ def test_header_is_plain_c(tmp_path):
     res = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src),
                           "-I", str(header.parent), "-o", str(tmp_path / "use.o")], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_hand_counted_waits_touch_no_inflight_register():
+    """k_stft_frames loads its samples with inline asm and waits with a hand-counted vmcnt: the compiler does
+    not know those registers are in flight.  scripts/check_inflight_regs.py compiles the device code and proves
+    on the ISA that nothing reads, writes, copies or spills them before the wait, and that the store block the
+    count relies on has exactly that many vector-memory operations (hipcc only, no GPU)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    done = subprocess.run([sys.executable, str(root / "scripts" / "check_inflight_regs.py")], capture_output=True, text=True)
+    assert done.returncode == 0, done.stdout + done.stderr
+    assert "ok (3 kernels)" in done.stdout
