@@ -33,13 +33,6 @@ namespace serhip {
 #ifndef SERHIP_K1_OPAQUE_LANE
 #define SERHIP_K1_OPAQUE_LANE 0
 #endif
-#ifndef SERHIP_K1_PREFETCH
-#define SERHIP_K1_PREFETCH 0
-#endif
-// Frame loads as inline asm with hand-counted waits (see k_stft_frames, "sample loads").
-#ifndef SERHIP_K1_ASMLOAD
-#define SERHIP_K1_ASMLOAD 1
-#endif
 #ifndef SERHIP_K1_OPAQUE_LOAD
 #define SERHIP_K1_OPAQUE_LOAD 1
 #endif
@@ -49,6 +42,9 @@ namespace serhip {
 // Diagnostic build only (-DSERHIP_K1_STAMPS=1): per-phase shader-cycle sums of every wave, taken with s_memtime
 // at the points where the wave already waits for lgkmcnt(0) (s_memtime shares that counter with LDS), written
 // to Scratch::mel (unused by this kernel) at the end.  Never in a timed or shipped build.
+#ifndef SERHIP_K1_WAIT_FENCED
+#define SERHIP_K1_WAIT_FENCED 1
+#endif
 #ifndef SERHIP_K1_STAMPS
 #define SERHIP_K1_STAMPS 0
 #endif
@@ -223,15 +219,43 @@ template <int kImm>
 __device__ __forceinline__ void load_pair_async(v2f& dst, const float* sbase, unsigned voff) {
     asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(kImm));
 }
-// wait until at most kYounger vector-memory operations of this wave are outstanding, and tie the 16 loaded
-// pairs to the wait so that no use of them can be scheduled above it
+// One-lane stores of the store block: issued with EXEC narrowed to lane 0 inside the asm statement instead of an
+// `if (lane == 0)` around a plain store.  The branch the compiler puts around such an `if` (s_cbranch_execz) is
+// never taken here, but a path-insensitive count of the block's operations cannot know that; and letting all 64
+// lanes store the same value to the same place moves 64 times the data into the memory pipeline (measured: 2 % of
+// the kernel).  Vector stores; the scalar data cache is not written.
+__device__ __forceinline__ void store_lane0(int* dst_uniform, int value) {
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_store_dword %1, %2, %3\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(0), "v"(value), "s"(dst_uniform) : "memory");
+}
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_lane0(float4* dst_uniform, v4f value) {
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_store_dwordx4 %1, %2, %3\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(0), "v"(value), "s"(dst_uniform) : "memory");
+}
+
+// Wait until at most kYounger vector-memory operations of this wave are outstanding.  No register operands on
+// purpose: tying the loaded registers to this statement ("+v") made the register allocator copy them into fresh
+// registers in FRONT of the wait -- a read of registers still in flight.  Instead nothing may be scheduled across
+// the statement (sched_barrier), every use of the loaded pairs follows it in program order, and
+// scripts/check_inflight_regs.py proves on the ISA that no instruction touches those registers before it.
 template <int kYounger>
-__device__ __forceinline__ void wait_pairs(v2f (&v)[16]) {
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-                 : "n"(kYounger));
-    asm volatile(""
-                 : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+__device__ __forceinline__ void wait_samples() {
+#if SERHIP_K1_WAIT_FENCED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
+#if SERHIP_K1_WAIT_FENCED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -330,42 +354,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         }
         return true;
     };
-    // frame t covers segment samples [t*512 - 1024, t*512 + 1024); lane l holds the 16 sample
-    // pairs 128*n1 + 2*l.  Out-of-range samples are the zero padding of librosa.stft(center=True).
-    auto load_frame = [&, lane_outer = lane](int t, v2f (&dst)[16]) {
-#if SERHIP_K1_OPAQUE_LOAD
-        int lane = lane_outer;
-        asm volatile("" : "+v"(lane));
-#else
-        const int lane = lane_outer;
-#endif
-        const int fs = t * kHop - kNfft / 2;   // < 2^31: the host rejects longer segments
-        const float* seg_audio = audio + sd.offset;
-        const bool aligned = ((reinterpret_cast<uintptr_t>(seg_audio) & 7u) == 0);
-        if (fs >= 0 && fs + kNfft <= sd.len) {
-            const float* p = seg_audio + fs + 2 * lane;
-            if (aligned) {
-#pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) dst[n1] = *reinterpret_cast<const v2f*>(p + 128 * n1);
-            } else {
-#pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) dst[n1] = v2f{p[128 * n1], p[128 * n1 + 1]};
-            }
-        } else {
-            // frame overlaps the zero padding: clamped (always valid) addresses, values masked afterwards
-            const int hi = sd.len - 1;
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int s = fs + 128 * n1 + 2 * lane;
-                const float a = seg_audio[min(max(s, 0), hi)];
-                const float b = seg_audio[min(max(s + 1, 0), hi)];
-                dst[n1] = v2f{static_cast<unsigned>(s) < static_cast<unsigned>(sd.len) ? a : 0.0f,
-                              static_cast<unsigned>(s + 1) < static_cast<unsigned>(sd.len) ? b : 0.0f};
-            }
-        }
-    };
-#if SERHIP_K1_ASMLOAD
-    // ---- sample loads.  The 16 loads of the NEXT frame are issued as soon as the unpack of the frame in hand
+    // ---- sample loads.  Frame t covers segment samples [t*512 - 1024, t*512 + 1024); lane l holds the 16 sample
+    // pairs 128*n1 + 2*l; out-of-range samples are the zero padding of librosa.stft(center=True).
+    // The 16 loads of the NEXT frame are issued as soon as the unpack of the frame in hand
     // has released the transform's registers, i.e. before that frame's stores; they are waited for at the top
     // of the next transform.  vmcnt counts loads and stores together, in order, and a store's acknowledgement
     // takes as long as a load from HBM: a compiler-placed wait (vmcnt(0) as soon as a conditional store sits
@@ -381,7 +372,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         asm volatile("" : "+v"(lane));
         const int fs = t * kHop - kNfft / 2;   // < 2^31: the host rejects longer segments
         const float* seg_audio = audio + sd.offset;
-        if (fs >= 0 && fs + kNfft <= sd.len) {
+        if ((fs >= 0) & (fs + kNfft <= sd.len)) {
             const float* b0 = seg_audio + fs;
             const float* b1 = b0 + 1024;       // immediate offsets reach 4 KiB
             const unsigned voff = 8u * static_cast<unsigned>(lane);
@@ -418,7 +409,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     auto fix_padded_frame = [&, lane_outer = lane](int t, v2f (&dst)[16]) {
         const int lane = lane_outer;
         const int fs = t * kHop - kNfft / 2;
-        if (fs >= 0 && fs + kNfft <= sd.len) return;
+        if ((fs >= 0) & (fs + kNfft <= sd.len)) return;
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int sx = fs + 128 * n1 + 2 * lane;
@@ -427,7 +418,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             dst[n1] = v2f{whole ? dst[n1].x : (last ? dst[n1].y : 0.0f), whole ? dst[n1].y : 0.0f};
         }
     };
-#endif
     const v2f rot3 = (q == 3) ? v2f{0.0f, -1.0f} : v2f{1.0f, 0.0f};   // lane 3 of a quad turns by -i
     // bit r: bin lane + 64 r lies in the piptrack range [kmin, kmax] (one VGPR instead of a set of
     // hoisted scalar conditions per stripe, which spilled SGPRs)
@@ -440,22 +430,22 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     unsigned stamp_frames = 0;
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
     const unsigned long long stamp_first = stamp_prev;
+    const unsigned long long stamp_real_first = __builtin_amdgcn_s_memrealtime();
 #endif
     // one frame, consumed from v (the raw sample pairs loaded by load_frame)
-    auto transform_frame = [&](v2f (&v)[16]) {
-        // s_win holds HALF the Hann window: the FFT is linear and halving is exact, so the unpack below
-        // needs no 0.5 factors
+    // s_win holds HALF the Hann window: the FFT is linear and halving is exact, so the unpack below needs no
+    // 0.5 factors.  The window is read from LDS BEFORE the wait for the samples (nothing is scheduled across that
+    // wait, so the order in the source is the order in the code): its LDS latency runs under the vmcnt wait.
+    auto read_window = [&](float4 (&w)[8]) {
 #pragma unroll
-        for (int n1 = 0; n1 < 16; n1 += 2) {
-            const float4 w = s_win4[(n1 >> 1) * 64 + lane];
-            v[n1] = v[n1] * v2f{w.x, w.y};
-            v[n1 + 1] = v[n1 + 1] * v2f{w.z, w.w};
+        for (int j = 0; j < 8; ++j) w[j] = s_win4[j * 64 + lane];
+    };
+    auto transform_frame = [&](v2f (&v)[16], const float4 (&w)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[2 * j] = v[2 * j] * v2f{w[j].x, w[j].y};
+            v[2 * j + 1] = v[2 * j + 1] * v2f{w[j].z, w[j].w};
         }
-#if SERHIP_K1_STAMPS && !SERHIP_K1_ASMLOAD
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) asm volatile("" : "+v"(v[n1]));
-#endif
         K1_STAMP(9)
 
         // ---- stage A: 16-pt DFT over n1 (registers), twiddle W_1024^(lane*k1), transpose
@@ -563,7 +553,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         wave_lds_sync();
         K1_STAMP(5)
 
-#if SERHIP_K1_ASMLOAD
         // ---- the segment's largest magnitude bounds its mel power from above: k_project_frames uses it to tell
         // which dB rows can never be clipped by top_db and need not be stored; the frame's own is piptrack's ref
         if (want_proj || want_chroma) cmax_bits = wave_max_bits(cmax_bits);
@@ -607,12 +596,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
                 first_peak = piptrack_peak<true>(sM[k - 1], sM[k], sM[k + 1], k, sr_d, static_cast<double>(kNfft));
             }
         }
+        if (want_proj) {
+            if (lane == 0) atomicMax(&sc.seg_cmax[seg], cmax_bits);   // ahead of the store block: lane 0 only
+        }
         // ---- store block: the LAST vector-memory operations of a frame, and always the same number of them
-        // (kStoresChroma + kStoresProj, by the plan's flags), so that the next frame can wait for its samples
-        // with an exact count (see "sample loads").  Lane 0 takes part in every one of them.
+        // (kStoreBlock, by the kernel's template flags), so that the next frame can wait for its samples with an
+        // exact count (see "sample loads").  No branch around any of them, so the count holds on every path
+        // (scripts/check_inflight_regs.py): one-lane stores narrow EXEC inside their asm statement (store_lane0).
         if (want_chroma) {
-            if (lane < base || lane == 0) prow[lane] = first_peak;   // slot 0 exists (peak_cap >= 8); count 0 says ignore it
-            if (lane == 0) sc.peak_cnt[row] = base;
+            // lanes without a peak fill unused slots of the row (slot peak_cap - 1 is never a peak: the host
+            // sizes rows two past the largest possible count)
+            prow[min(lane, sc.peak_cap - 1)] = lane < base ? first_peak : v2f{0.0f, 0.0f};
+            store_lane0(sc.peak_cnt + row, base);
         }
         if (want_proj) {
             // magnitudes for k_project_frames: a linear copy of sM, float4 chunk (lane + 64u) per lane
@@ -622,73 +617,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             float4* m4 = reinterpret_cast<float4*>(sc.mags);
 #pragma unroll
             for (int u = 0; u < 4; ++u) m4[mags_tile_index(row, lane + 64 * u)] = mp[lane + 64 * u];
-            if (lane == 0) m4[mags_tile_index(row, 256)] = float4{mhi[0], 0.0f, 0.0f, 0.0f};
-            if (lane == 0) atomicMax(&sc.seg_cmax[seg], cmax_bits);
+            store_lane0(m4 + mags_tile_index(row, 256), v4f{mhi[0], 0.0f, 0.0f, 0.0f});   // lane 0 holds bin 1024
         }
         wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
         K1_STAMP(7)
     };
-#else
-        // ---- magnitudes for k_project_frames: a linear copy of sM, float4 chunk (lane + 64u) per lane
-        // (conflict-free ds_read_b128; eight whole 128-byte lines per store instruction); bin 1024 is
-        // stored with three zero pads so the last 16-bin group reads defined values
-        if (want_proj) {
-            const float4* mp = reinterpret_cast<const float4*>(sM);
-            float4* m4 = reinterpret_cast<float4*>(sc.mags);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) m4[mags_tile_index(row, lane + 64 * u)] = mp[lane + 64 * u];
-            if (lane == 0) m4[mags_tile_index(row, 256)] = float4{mhi[0], 0.0f, 0.0f, 0.0f};
-        }
-
-        // ---- piptrack peaks (bins kmin..kmax), threshold 0.1 * column max.  Pass 1 finds the local
-        // maxima and compacts their bin numbers into LDS; pass 2 gives each lane one peak, so the
-        // double-precision interpolation runs once per 64 peaks instead of once per bin stripe.
-        // the segment's largest magnitude bounds its mel power from above: k_project_frames uses it to
-        // tell which dB rows can never be clipped by top_db and need not be stored
-        if (want_proj) {
-            cmax_bits = wave_max_bits(cmax_bits);
-            if (lane == 0) atomicMax(&sc.seg_cmax[seg], cmax_bits);
-        }
-        K1_STAMP(0)
-        if (want_chroma) {
-            const float cmax = __uint_as_float(cmax_bits);
-            const float ref = 0.1f * cmax;
-            int* cand = reinterpret_cast<int*>(fbuf + 1032);   // behind sM
-            int base = 0;
-            // librosa thresholds S below ref to 0 before localmax; with s0 > ref that is the same as
-            // comparing the raw neighbours (a neighbour <= ref is < s0 either way)
-            auto scan_stripe = [&](int r, float s0) {
-                const int k = lane + 64 * r;
-                const bool cand_ok = (s0 > ref) & (((in_range >> r) & 1u) != 0u);
-                if (__ballot(cand_ok) == 0ull) return;   // wave-uniform: most stripes hold nothing above ref
-                // both neighbours are read unconditionally and the tests combined without short-circuit
-                // branches: one LDS round trip per stripe instead of two nested ones
-                const float sm = sM[max(k - 1, 0)], sp = sM[k + 1];
-                const bool is_peak = cand_ok & (s0 > sm) & (s0 >= sp);
-                const unsigned long long mask = __ballot(is_peak);
-                if (is_peak) cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = k;
-                base += __popcll(mask);
-            };
-#pragma unroll
-            for (int r = 0; r < 8; ++r) scan_stripe(r, mlo[r]);
-            for (int r = 8; 64 * r <= tb.kmax; ++r) scan_stripe(r, sM[lane + 64 * r]);   // sample rates < 16 kHz
-            wave_lds_sync();
-        K1_STAMP(6)
-            v2f* prow = sc.peaks + row * sc.peak_cap;
-            for (int i = lane; i < base; i += 64) {
-                const int k = cand[i];
-                prow[i] = piptrack_peak<true>(sM[k - 1], sM[k], sM[k + 1], k, sr_d, static_cast<double>(kNfft));
-            }
-            if (lane == 0) sc.peak_cnt[row] = base;
-        }
-        wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
-        K1_STAMP(7)
-    };
-
-#endif
-#if SERHIP_K1_ASMLOAD
     // vector-memory operations in the store block of finish_frame
-    constexpr int kStoreBlock = (kChroma ? 2 : 0) + (kProj ? 6 : 0);
+    constexpr int kStoreBlock = (kChroma ? 2 : 0) + (kProj ? 5 : 0);
     v2f v[16];
     bool more = seek();
     if (more) {
@@ -696,7 +631,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         // the first frame has no predecessor whose store block would follow its loads: stand-ins, so that the
         // one wait below is right for every frame (the stored value is what the frame will store there anyway
         // or overwrite: its own peak count slot)
-        if (lane == 0) {
+        {
             volatile int* slot = sc.peak_cnt + static_cast<size_t>(sd.stft_base) + static_cast<size_t>(wu.t_begin + (pos - base));
 #pragma unroll
             for (int i = 0; i < kStoreBlock; ++i) *slot = 0;   // volatile: kStoreBlock separate store instructions
@@ -707,10 +642,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         const size_t row = static_cast<size_t>(sd.stft_base) + static_cast<size_t>(t);
         const int drawn = draw();
         const int seg = wu.seg;
+        float4 win[8];
+        read_window(win);
         // the samples of this frame: everything but the store block that followed their loads has to be done
-        wait_pairs<kStoreBlock>(v);
+        wait_samples<kStoreBlock>();
         fix_padded_frame(t, v);
-        transform_frame(v);
+        transform_frame(v, win);
         finish_frame(row, seg, [&]() {
             pos = __builtin_amdgcn_readfirstlane(drawn);
             more = seek();
@@ -721,44 +658,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         ++stamp_frames;
 #endif
     }
-#else
-    // The next frame's samples are requested after this frame's stores.  Requesting them earlier (into
-    // the registers the transform has released, ahead of the stores in the vmcnt queue) was measured
-    // twice, spill-free, and is 2-3 % slower: the waves do not wait on these loads.
-    v2f v[16];
-    bool more = seek();
-    if (more) load_frame(wu.t_begin + (pos - base), v);
-    while (more) {
-        const size_t row = static_cast<size_t>(sd.stft_base) + static_cast<size_t>(wu.t_begin + (pos - base));
-        const int drawn = draw();
-        const int seg = wu.seg;
-        transform_frame(v);
-#if SERHIP_K1_PREFETCH
-        // the next frame's samples are requested as soon as the unpack has released the transform's
-        // registers: the stores and the peak search of this frame (a third of its time) cover their latency
-        finish_frame(row, seg, [&]() {
-            pos = __builtin_amdgcn_readfirstlane(drawn);
-            more = seek();
-            if (more) load_frame(wu.t_begin + (pos - base), v);
-        });
-#else
-        finish_frame(row, seg, []() {});
-        pos = __builtin_amdgcn_readfirstlane(drawn);
-        more = seek();
-        if (more) load_frame(wu.t_begin + (pos - base), v);
-#endif
-        K1_STAMP(8)
-#if SERHIP_K1_STAMPS
-        ++stamp_frames;
-#endif
-    }
-#endif
 #if SERHIP_K1_STAMPS
     if (lane == 0) {
         unsigned* dst = reinterpret_cast<unsigned*>(sc.mel) + (blockIdx.x * kWaves + wave) * 16;
         for (int i = 0; i < 10; ++i) dst[i] = stamp_acc[i];
         dst[10] = stamp_frames;
         dst[11] = static_cast<unsigned>(__builtin_amdgcn_s_memtime() - stamp_first);
+        dst[12] = static_cast<unsigned>(__builtin_amdgcn_s_memrealtime() - stamp_real_first);   // 100 MHz ticks
+        dst[13] = static_cast<unsigned>(stamp_real_first);
     }
 #endif
 }

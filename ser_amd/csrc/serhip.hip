@@ -562,13 +562,21 @@ int launch_chunks(serhip_plan* plan, const CallPlan& cp, const Placement& pl, ch
                 (void)hipStreamSynchronize(stream);
                 std::vector<unsigned> st(static_cast<size_t>(c.wgs) * kWaves * 16);
                 (void)hipMemcpy(st.data(), sf.mel, st.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
-                double sum[12] = {0};
+                double sum[16] = {0};
                 for (size_t w = 0; w < static_cast<size_t>(c.wgs) * kWaves; ++w)
-                    for (int i = 0; i < 12; ++i) sum[i] += st[w * 16 + i];
+                    for (int i = 0; i < 13; ++i) sum[i] += st[w * 16 + i];
                 std::fprintf(stderr, "k1 stamps: frames/wave %.1f, cycles/frame total %.0f; phases:", sum[10] / (c.wgs * kWaves),
                              sum[11] / sum[10]);
                 for (int i = 0; i <= 9; ++i) std::fprintf(stderr, " P%d %.0f", i, sum[i] / sum[10]);
-                std::fprintf(stderr, "\n");
+                double lo = 1e30, hi = 0, t0 = 1e30, t1 = 0;
+                for (size_t w = 0; w < static_cast<size_t>(c.wgs) * kWaves; ++w) {
+                    lo = std::min(lo, static_cast<double>(st[w * 16 + 12]));
+                    hi = std::max(hi, static_cast<double>(st[w * 16 + 12]));
+                    t0 = std::min(t0, static_cast<double>(st[w * 16 + 13]));
+                    t1 = std::max(t1, static_cast<double>(st[w * 16 + 13]) + st[w * 16 + 12]);
+                }
+                std::fprintf(stderr, "   clock %.3f GHz; wave lifetime min %.3f max %.3f ms; first start to last end %.3f ms\n",
+                             sum[11] / sum[12] * 0.1, lo * 1e-5, hi * 1e-5, (t1 - t0) * 1e-5);
             }
 #endif
             const dim3 segs_grid(static_cast<unsigned>(c.count));

@@ -160,3 +160,21 @@ def test_hand_counted_waits_touch_no_inflight_register():
     done = subprocess.run([sys.executable, str(root / "scripts" / "check_inflight_regs.py")], capture_output=True, text=True)
     assert done.returncode == 0, done.stdout + done.stderr
     assert "ok (3 kernels)" in done.stdout
+    # the checker is not vacuous: a copy of a register in flight, or one store fewer in the block, is caught
+    import re
+
+    sys.path.insert(0, str(root / "scripts"))
+    import check_inflight_regs as chk
+
+    text = chk.device_asm().split("\n")
+    start = next(i for i, l in enumerate(text) if l.startswith("_ZN6serhip13k_stft_framesILb1ELb1EE"))
+    end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))
+    body = text[start + 1:end]
+    assert chk.check_kernel("clean", body) == []
+    loads = [i for i, l in enumerate(body) if "global_load_dwordx2" in l and "ASMSTART" in body[i - 1]]
+    dest = re.search(r"global_load_dwordx2 v\[(\d+):", body[loads[-1]]).group(1)
+    bad = body[:loads[-1] + 2] + [f"\tv_mov_b32_e32 v127, v{dest}"] + body[loads[-1] + 2:]
+    assert any("touches registers in flight" in p for p in chk.check_kernel("copy", bad))
+    stores = [i for i, l in enumerate(body) if "global_store_dwordx4" in l]
+    fewer = body[:stores[-1]] + body[stores[-1] + 1:]
+    assert any("sure to follow the loads" in p for p in chk.check_kernel("fewer", fewer))
