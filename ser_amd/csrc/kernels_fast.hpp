@@ -615,15 +615,28 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             // stored with three zero pads so the last 16-bin group reads defined values
             const float4* mp = reinterpret_cast<const float4*>(sM);
             float4* m4 = reinterpret_cast<float4*>(sc.mags);
+#if SERHIP_EXP_K1_HOT_STORES   // timing experiment: every frame's magnitudes land in the first 1024 rows (L2-resident)
+            const size_t mrow = row & 1023;
+#else
+            const size_t mrow = row;
+#endif
 #pragma unroll
-            for (int u = 0; u < 4; ++u) m4[mags_tile_index(row, lane + 64 * u)] = mp[lane + 64 * u];
-            store_lane0(m4 + mags_tile_index(row, 256), v4f{mhi[0], 0.0f, 0.0f, 0.0f});   // lane 0 holds bin 1024
+#if SERHIP_EXP_K1_ST34        // timing experiment: three quarters of the magnitude bytes
+            for (int u = 0; u < 3; ++u) m4[mags_tile_index(mrow, lane + 64 * u)] = mp[lane + 64 * u];
+#else
+            for (int u = 0; u < 4; ++u) m4[mags_tile_index(mrow, lane + 64 * u)] = mp[lane + 64 * u];
+#endif
+            store_lane0(m4 + mags_tile_index(mrow, 256), v4f{mhi[0], 0.0f, 0.0f, 0.0f});   // lane 0 holds bin 1024
         }
         wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
         K1_STAMP(7)
     };
     // vector-memory operations in the store block of finish_frame
+#if SERHIP_EXP_K1_ST34
+    constexpr int kStoreBlock = (kChroma ? 2 : 0) + (kProj ? 4 : 0);
+#else
     constexpr int kStoreBlock = (kChroma ? 2 : 0) + (kProj ? 5 : 0);
+#endif
     v2f v[16];
     bool more = seek();
     if (more) {

@@ -24,6 +24,44 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kProjTile = 32;   // frames per wave
 constexpr int kProjWaves = 3;   // waves per workgroup: one B row each to fetch; 96 frames = one 3 s clip
 
+// v[l] (+|min) v[l ^ 16] and v[l ^ 32] in every lane without an LDS round trip: v_permlane16_swap /
+// v_permlane32_swap (gfx950) of two copies of v leave {rows 0,0,2,2 | rows 1,1,3,3} and {lower half twice | upper
+// half twice}.  The operands are the same two numbers a __shfl_xor butterfly would combine, so the sums are
+// bit-identical to it.
+__device__ __forceinline__ float sum_xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float min_xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float min_xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+template <bool k32>
+__device__ __forceinline__ double sum_xor_rows(double v) {
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+    const unsigned lo = static_cast<unsigned>(b), hi = static_cast<unsigned>(b >> 32);
+    const auto rl = k32 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = k32 ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false) : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double a = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(rh[0]) << 32) | rl[0]));
+    const double c = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(rh[1]) << 32) | rl[1]));
+    return a + c;
+}
+// max over each row of 16 lanes, in every lane of the row (the first four steps of wave_max)
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
+    return fmaxf(v, dpp_mov<0x140>(v));   // row_mirror
+}
+
 __device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
@@ -103,19 +141,16 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
                         dmin = fminf(dmin, db[r]);
                     }
                 }
-                if (-wave_max(-dmin) < store_below) {   // wave-uniform: some value of this block may be clipped
+                if (__any(dmin < store_below)) {   // wave-uniform: some value of this block may be clipped
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (tb0 + 4 * kk + r < sd.n_stft)
                             mel_out[static_cast<size_t>(16 * h + r) * kMels + 16 * cur] = db[r];
                 }
                 // the four lanes (kk = 0..3) that hold one filter's 16 frames
-                psum += __shfl_xor(psum, 16);
-                psum += __shfl_xor(psum, 32);
-                dsum += __shfl_xor(dsum, 16);
-                dsum += __shfl_xor(dsum, 32);
-                dmin = fminf(dmin, __shfl_xor(dmin, 16));
-                dmin = fminf(dmin, __shfl_xor(dmin, 32));
+                psum = sum_xor32(sum_xor16(psum));
+                dsum = sum_xor_rows<true>(sum_xor_rows<false>(dsum));
+                dmin = min_xor32(min_xor16(dmin));
                 dmax = wave_max(dmax);
                 const size_t tile = (f0 >> 4) + h;
                 if (kk == 0) {
@@ -232,9 +267,7 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
             for (int r = 0; r < 4; ++r) {
                 const int t = t0 + 16 * half + 4 * kk + r;
                 const float raw = c[r];
-                float mx = fabsf(raw);
-#pragma unroll
-                for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                float mx = row_max(fabsf(raw));
                 if (mx < tiny) mx = 1.0f;
                 if (t < sd.n_stft) sc.chroma_norm[(static_cast<size_t>(sd.stft_base) + t) * 16 + i] = raw / mx;
             }
