@@ -224,11 +224,16 @@ __device__ __forceinline__ void load_pair_async(v2f& dst, const float* sbase, un
 // never taken here, but a path-insensitive count of the block's operations cannot know that; and letting all 64
 // lanes store the same value to the same place moves 64 times the data into the memory pipeline (measured: 2 % of
 // the kernel).  Vector stores; the scalar data cache is not written.
+#if SERHIP_EXP_K1_NT_ALL   // experiment: every store of the store block streaming
+#define SERHIP_LANE0_NT " nt"
+#else
+#define SERHIP_LANE0_NT ""
+#endif
 __device__ __forceinline__ void store_lane0(int* dst_uniform, int value) {
     unsigned long long saved;
     asm volatile("s_mov_b64 %0, exec\n\t"
                  "s_mov_b64 exec, 1\n\t"
-                 "global_store_dword %1, %2, %3\n\t"
+                 "global_store_dword %1, %2, %3" SERHIP_LANE0_NT "\n\t"
                  "s_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(0), "v"(value), "s"(dst_uniform) : "memory");
 }
@@ -237,7 +242,7 @@ __device__ __forceinline__ void store_lane0(float4* dst_uniform, v4f value) {
     unsigned long long saved;
     asm volatile("s_mov_b64 %0, exec\n\t"
                  "s_mov_b64 exec, 1\n\t"
-                 "global_store_dwordx4 %1, %2, %3\n\t"
+                 "global_store_dwordx4 %1, %2, %3" SERHIP_LANE0_NT "\n\t"
                  "s_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(0), "v"(value), "s"(dst_uniform) : "memory");
 }
@@ -606,7 +611,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         if (want_chroma) {
             // lanes without a peak fill unused slots of the row (slot peak_cap - 1 is never a peak: the host
             // sizes rows two past the largest possible count)
+#if SERHIP_EXP_K1_NT_ALL
+            __builtin_nontemporal_store(lane < base ? first_peak : v2f{0.0f, 0.0f}, &prow[min(lane, sc.peak_cap - 1)]);
+#else
             prow[min(lane, sc.peak_cap - 1)] = lane < base ? first_peak : v2f{0.0f, 0.0f};
+#endif
             store_lane0(sc.peak_cnt + row, base);
         }
         if (want_proj) {
@@ -623,8 +632,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
 #pragma unroll
 #if SERHIP_EXP_K1_ST34        // timing experiment: three quarters of the magnitude bytes
             for (int u = 0; u < 3; ++u) m4[mags_tile_index(mrow, lane + 64 * u)] = mp[lane + 64 * u];
-#else
+#elif SERHIP_EXP_K1_PLAIN_STORES   // experiment: the default cache policy
             for (int u = 0; u < 4; ++u) m4[mags_tile_index(mrow, lane + 64 * u)] = mp[lane + 64 * u];
+#else
+            // streaming (nt) stores: the rows are read once, by another kernel, long after they have left the L2;
+            // store acknowledgements come back sooner and with them the in-order vmcnt of the next sample loads
+            // (measured: kernel -3.7 %)
+            for (int u = 0; u < 4; ++u) {
+                const float4 val = mp[lane + 64 * u];
+                __builtin_nontemporal_store(v4f{val.x, val.y, val.z, val.w}, reinterpret_cast<v4f*>(m4 + mags_tile_index(mrow, lane + 64 * u)));
+            }
 #endif
             store_lane0(m4 + mags_tile_index(mrow, 256), v4f{mhi[0], 0.0f, 0.0f, 0.0f});   // lane 0 holds bin 1024
         }

@@ -62,6 +62,16 @@ __device__ __forceinline__ float row_max(float v) {
     return fmaxf(v, dpp_mov<0x140>(v));   // row_mirror
 }
 
+// magnitude fragment load; SERHIP_EXP_K2_NT_LOADS marks it streaming (nt)
+__device__ __forceinline__ float4 load_mags(const float4* p) {
+#if SERHIP_EXP_K2_NT_LOADS
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return float4{v[0], v[1], v[2], v[3]};
+#else
+    return *p;
+#endif
+}
+
 __device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     // they are the two halves of the same 128-byte lines, and requested back to back the second load
     // finds the lines the first one brought (a step apart it found them evicted: +17 % kernel time).
     for (int j = threadIdx.x; j < kGroups; j += kProjWaves * 64) s_prog[j] = tb.mel_prog[j];
-    float4 aE0 = a0p[0], aE1 = a1p[0], aO0 = a0p[mags_group_offset(1)], aO1 = a1p[mags_group_offset(1)];
+    float4 aE0 = load_mags(a0p), aE1 = load_mags(a1p), aO0 = load_mags(a0p + mags_group_offset(1)), aO1 = load_mags(a1p + mags_group_offset(1));
     float4 aP0, aP1;
     __syncthreads();
     float4 bE = fetch_b(0, prog_at(0));
@@ -231,10 +241,10 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
         bE = fetch_b(G + 2, prog_at(G + 2));            // G + 2 <= 64
         compute(G, aE0, aE1, prog_at(G));
         s_b[1][wave][lane] = bO;                        // B rows of G + 1
-        aE0 = a0p[mags_group_offset(G + 2)];
-        aE1 = a1p[mags_group_offset(G + 2)];
-        an0 = a0p[mags_group_offset(G + 3)];            // G + 3 = 65 at the end: the unused half of the last block
-        an1 = a1p[mags_group_offset(G + 3)];
+        aE0 = load_mags(a0p + mags_group_offset(G + 2));
+        aE1 = load_mags(a1p + mags_group_offset(G + 2));
+        an0 = load_mags(a0p + mags_group_offset(G + 3));            // G + 3 = 65 at the end: the unused half of the last block
+        an1 = load_mags(a1p + mags_group_offset(G + 3));
         __syncthreads();
         // odd group G + 1: stage 1
         const int G3 = min(G + 3, kGroups - 1);         // the last odd step fetches a B row nobody uses
