@@ -224,11 +224,7 @@ __device__ __forceinline__ void load_pair_async(v2f& dst, const float* sbase, un
 // never taken here, but a path-insensitive count of the block's operations cannot know that; and letting all 64
 // lanes store the same value to the same place moves 64 times the data into the memory pipeline (measured: 2 % of
 // the kernel).  Vector stores; the scalar data cache is not written.
-#if SERHIP_EXP_K1_NT_ALL   // experiment: every store of the store block streaming
-#define SERHIP_LANE0_NT " nt"
-#else
 #define SERHIP_LANE0_NT ""
-#endif
 __device__ __forceinline__ void store_lane0(int* dst_uniform, int value) {
     unsigned long long saved;
     asm volatile("s_mov_b64 %0, exec\n\t"
@@ -236,6 +232,16 @@ __device__ __forceinline__ void store_lane0(int* dst_uniform, int value) {
                  "global_store_dword %1, %2, %3" SERHIP_LANE0_NT "\n\t"
                  "s_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(0), "v"(value), "s"(dst_uniform) : "memory");
+}
+// the same for a run of lanes: lanes whose bit is set in `mask` (wave-uniform, never 0) store 8 bytes to
+// row_uniform + voff.  One vector-memory operation on every path, whatever the mask.
+__device__ __forceinline__ void store_pairs_masked(v2f* row_uniform, unsigned voff, v2f value, unsigned long long mask) {
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "global_store_dwordx2 %1, %2, %3\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(voff), "v"(value), "s"(row_uniform), "s"(mask) : "memory");
 }
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_lane0(float4* dst_uniform, v4f value) {
@@ -609,12 +615,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         // exact count (see "sample loads").  No branch around any of them, so the count holds on every path
         // (scripts/check_inflight_regs.py): one-lane stores narrow EXEC inside their asm statement (store_lane0).
         if (want_chroma) {
+#if SERHIP_EXP_K1_PEAKS_ALL_LANES
             // lanes without a peak fill unused slots of the row (slot peak_cap - 1 is never a peak: the host
             // sizes rows two past the largest possible count)
-#if SERHIP_EXP_K1_NT_ALL
-            __builtin_nontemporal_store(lane < base ? first_peak : v2f{0.0f, 0.0f}, &prow[min(lane, sc.peak_cap - 1)]);
-#else
             prow[min(lane, sc.peak_cap - 1)] = lane < base ? first_peak : v2f{0.0f, 0.0f};
+#else
+            // only the lanes that hold a peak store (lane 0 always does, a zero pair into slot 0 of a frame without
+            // peaks: nobody reads it, the count says 0): EXEC is set from the count inside the asm statement
+            {
+                const int n = __builtin_amdgcn_readfirstlane(min(max(base, 1), 64));
+                const unsigned long long mask = n == 64 ? ~0ull : (1ull << n) - 1ull;
+                store_pairs_masked(prow, static_cast<unsigned>(lane) * 8u, lane < base ? first_peak : v2f{0.0f, 0.0f}, mask);
+            }
 #endif
             store_lane0(sc.peak_cnt + row, base);
         }
