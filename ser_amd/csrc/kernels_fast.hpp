@@ -118,7 +118,7 @@ struct Scratch {
     double* mel_dbsum;    // [frames/16][128]  fast path: dB values summed over the 16 frames of a tile
     float* mel_dbmin;     // [frames/16][128]  fast path: smallest dB value of the tile
     v2f* peaks;           // [frames][peak_cap]  (pitch, mag)
-    int* peak_cnt;        // [frames]
+    int* peak_cnt;        // [frames] fast path: peak count | frame-max key (see kPeakCountMask); generic path: the count
     float* chroma_norm;   // [frames][16]  per-frame inf-normalised chroma (classes 12..15 unused)
     int* tuning_idx;      // [segments of the chunk]
     unsigned* seg_cmax;   // [segments of the chunk] bit pattern of the segment's largest |X| (atomicMax, zeroed per call)
@@ -139,6 +139,12 @@ __host__ __device__ __forceinline__ size_t mags_tile_index(size_t f, int q) {
     return (f >> 4) * kTileF4 + static_cast<size_t>(q >> 3) * 128 + (f & 15) * 8 + (q & 7);
 }
 // float4 offset, inside a tile, of MFMA group G (16 bins) for lane (frame 0, kk 0)
+// k_stft_frames packs two things into a frame's peak_cnt word: the peak count in the low 10 bits and, above them,
+// the bit pattern of an UPPER bound of the frame's largest magnitude (rounded up to a multiple of 1024 in bit
+// space, i.e. by at most 2^-13 relative).  k_segment_finish<1> reads the counts anyway and takes the maximum of the
+// keys as the segment's bound for k_project_frames' row-store test -- which only needs a bound, so the results do
+// not change -- instead of one atomicMax per frame from the FFT kernel (5 % of that kernel).
+constexpr unsigned kPeakCountMask = 1023u;
 __host__ __device__ __forceinline__ int mags_group_offset(int G) { return (G >> 1) * 128 + (G & 1) * 4; }
 
 template <int CTRL>
@@ -511,6 +517,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     };
     // second half of a frame: Z (in this wave's LDS buffer) -> |X|, stores, peaks.  Needs no registers
     // of the transform, so the next frame's samples are requested before it starts.
+    int run_seg = -1;        // segment of the frames whose largest magnitude run_max holds (see finish_frame)
+    unsigned run_max = 0;
     auto finish_frame = [&, lane_outer = lane](size_t row, int seg, auto&& after_unpack) {
 #if SERHIP_K1_OPAQUE_LANE
         // an opaque copy of the lane id: the addresses derived from it are recomputed per frame instead of
@@ -608,7 +616,24 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             }
         }
         if (want_proj) {
-            if (lane == 0) atomicMax(&sc.seg_cmax[seg], cmax_bits);   // ahead of the store block: lane 0 only
+#if SERHIP_EXP_K1_CMAX_PER_FRAME     // the first form: one atomic per frame, 5 % of the kernel
+            if (lane == 0) atomicMax(&sc.seg_cmax[seg], cmax_bits);
+#else
+            // the segment's largest magnitude.  With chroma on it travels in the frame's peak-count word (store
+            // block below) and k_segment_finish<1> reduces it.  Without chroma that kernel does not run: the
+            // maximum is kept per wave over the consecutive frames it draws from one segment and sent as one
+            // atomic per such run, ahead of the store block (an atomic is acknowledged late and vmcnt counts in
+            // order, so each one delays the wave's next sample wait).
+            if constexpr (!kChroma) {
+                if (seg != run_seg) {
+                    if (run_seg >= 0 && lane == 0) atomicMax(&sc.seg_cmax[run_seg], run_max);
+                    run_seg = __builtin_amdgcn_readfirstlane(seg);
+                    run_max = __builtin_amdgcn_readfirstlane(cmax_bits);
+                } else {
+                    run_max = __builtin_amdgcn_readfirstlane(max(run_max, cmax_bits));
+                }
+            }
+#endif
         }
         // ---- store block: the LAST vector-memory operations of a frame, and always the same number of them
         // (kStoreBlock, by the kernel's template flags), so that the next frame can wait for its samples with an
@@ -625,10 +650,17 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             {
                 const int n = __builtin_amdgcn_readfirstlane(min(max(base, 1), 64));
                 const unsigned long long mask = n == 64 ? ~0ull : (1ull << n) - 1ull;
-                store_pairs_masked(prow, static_cast<unsigned>(lane) * 8u, lane < base ? first_peak : v2f{0.0f, 0.0f}, mask);
+                unsigned slot = static_cast<unsigned>(lane);
+                asm volatile("" : "+v"(slot));   // opaque: the byte offset is recomputed here, not kept in a register across the frame loop
+                store_pairs_masked(prow, slot * 8u, lane < base ? first_peak : v2f{0.0f, 0.0f}, mask);
             }
 #endif
+#if SERHIP_EXP_K1_CMAX_PER_FRAME
             store_lane0(sc.peak_cnt + row, base);
+#else
+            store_lane0(sc.peak_cnt + row, __builtin_amdgcn_readfirstlane(static_cast<int>(
+                            ((cmax_bits + kPeakCountMask) & ~kPeakCountMask) | static_cast<unsigned>(base))));
+#endif
         }
         if (want_proj) {
             // magnitudes for k_project_frames: a linear copy of sM, float4 chunk (lane + 64u) per lane
@@ -700,6 +732,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         ++stamp_frames;
 #endif
     }
+    if (kProj && !kChroma && run_seg >= 0 && lane == 0) atomicMax(&sc.seg_cmax[run_seg], run_max);
 #if SERHIP_K1_STAMPS
     if (lane == 0) {
         unsigned* dst = reinterpret_cast<unsigned*>(sc.mel) + (blockIdx.x * kWaves + wave) * 16;
@@ -780,7 +813,7 @@ __device__ __forceinline__ void for_each_peak(const Sh& sh, bool in_lds, const S
         const int nw = blockDim.x >> 6;
         for (int tb = wave; tb < sd.n_stft; tb += 64 * nw) {
             const int my_t = tb + lane * nw;
-            const int my_cnt = my_t < sd.n_stft ? sc.peak_cnt[static_cast<size_t>(sd.stft_base) + my_t] : 0;
+            const int my_cnt = my_t < sd.n_stft ? static_cast<int>(static_cast<unsigned>(sc.peak_cnt[static_cast<size_t>(sd.stft_base) + my_t]) & kPeakCountMask) : 0;
             const int rows = min(64, (sd.n_stft - tb + nw - 1) / nw);
             for (int r0 = 0; r0 < rows; r0 += 4) {
                 int c[4];
@@ -1090,15 +1123,27 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
     // free until the select) so that the gather below needs no dependent global loads
     const bool few_frames = sd.n_stft <= 1024;
     int total = 0;
+    unsigned frame_max = 0;   // largest frame-max key of the segment (kPeakCountMask)
     for (int t = tid; t < sd.n_stft; t += blockDim.x) {
-        const int c = sc.peak_cnt[static_cast<size_t>(sd.stft_base) + t];
+        const unsigned word = static_cast<unsigned>(sc.peak_cnt[static_cast<size_t>(sd.stft_base) + t]);
+        const int c = static_cast<int>(word & kPeakCountMask);
+        frame_max = max(frame_max, word & ~kPeakCountMask);
         total += c;
         if (few_frames) sh.hist[t] = static_cast<unsigned>(c);
     }
     total = wave_sum_int(total);
-    if (lane == 0) sh.ired[wave] = total;
+    frame_max = wave_max_bits(frame_max);
+    if (lane == 0) {
+        sh.ired[wave] = total;
+        sh.ired[4 + wave] = static_cast<int>(frame_max);
+    }
     __syncthreads();
     const int n_peaks = sh.ired[0] + sh.ired[1] + sh.ired[2] + sh.ired[3];
+    if constexpr (kMode == 1) {
+        if (tid == 0)
+            sc.seg_cmax[blockIdx.x] = max(max(static_cast<unsigned>(sh.ired[4]), static_cast<unsigned>(sh.ired[5])),
+                                          max(static_cast<unsigned>(sh.ired[6]), static_cast<unsigned>(sh.ired[7])));
+    }
     __syncthreads();
     const bool in_lds = n_peaks <= kPeakLdsCap;
     if (in_lds && few_frames) {
@@ -1159,7 +1204,7 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
     } else if (in_lds) {
         for (int t = wave; t < sd.n_stft; t += 4) {
             const size_t row = static_cast<size_t>(sd.stft_base) + t;
-            const int c = sc.peak_cnt[row];
+            const int c = static_cast<int>(static_cast<unsigned>(sc.peak_cnt[row]) & kPeakCountMask);
             if (c == 0) continue;
             int base = 0;
             if (lane == 0) base = atomicAdd(&sh.n_peaks, c);

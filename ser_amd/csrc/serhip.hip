@@ -913,6 +913,10 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
         tb.mel_wsum_max = static_cast<float>(wmax * (1.0 + 1e-6));
     }
     plan->peak_cap = std::max(8, (h.kmax - h.kmin + 2) / 2 + 2);
+    if (plan->peak_cap > static_cast<int>(kPeakCountMask)) {   // the count shares its word with the frame-max key
+        serhip_plan_destroy(plan);
+        return fail(SERHIP_E_UNSUPPORTED, "serhip_plan_fast: more peak candidates per frame than the count field holds");
+    }
     *out = plan;
     return SERHIP_OK;
 }
