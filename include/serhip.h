@@ -184,6 +184,26 @@ int serhip_mlp_predict(serhip_ctx* ctx, const void* x_dev, int x_is_f64, int64_t
                        const double* const* bias_dev, int hidden_activation, int out_activation,
                        double* proba_dev, int32_t* label_dev, void* stream);
 
+/* Fan-in of the per-GPU feature shards: one process per GPU, contiguous shards by segment, ONE collective at
+ * the end.  Replaces the result collection of the reference's multiprocessing.Pool over files
+ * (ser/_internal/data/data_loader.py:368-379, pool.imap_unordered -> list) for a multi-GPU host that does not go
+ * through torch.distributed (ser_amd/distributed.py is the torch form of the same gather).  RCCL is loaded on
+ * first use (dlopen of librccl.so.1; libserhip.so has no link-time dependency on it).
+ *   serhip_comm_unique_id   rank 0 calls it and hands the SERHIP_COMM_ID_BYTES bytes to the other ranks by any
+ *                           means the host has (a file, MPI, a socket)
+ *   serhip_comm_create      collective over all `world` ranks: joins the communicator on the context's GPU
+ *   serhip_allgather_rows   out_dev[sum(rows_per_rank), dim] = the shards [rows_per_rank[r], dim] of all ranks in
+ *                           rank order, on every rank; rows_per_rank is a HOST array [world] (shards may differ in
+ *                           size, and may be empty); shard_dev holds this rank's rows_per_rank[rank] rows.
+ *                           Enqueued on `stream` (one grouped RCCL call: a broadcast per non-empty shard). */
+#define SERHIP_COMM_ID_BYTES 128
+typedef struct serhip_comm serhip_comm;
+int serhip_comm_unique_id(unsigned char* id_out);
+int serhip_comm_create(serhip_ctx* ctx, const unsigned char* id, int rank, int world, serhip_comm** out);
+int serhip_allgather_rows(serhip_comm* comm, const float* shard_dev, const int64_t* rows_per_rank, int32_t dim,
+                          float* out_dev, void* stream);
+void serhip_comm_destroy(serhip_comm* comm);
+
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on.
  * No reference counterpart (the reference's only timer is the phase stopwatch of
  * ser/_internal/runtime/phase_timing.py:29-78 around whole inferences); bench.py uses

@@ -51,6 +51,10 @@ SIGNATURES: dict[str, tuple] = {
          POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p, c_void_p],
     ),
     "serhip_tuning_from_peaks": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int32), c_int32, POINTER(c_float)]),
+    "serhip_comm_unique_id": (c_int, [c_void_p]),
+    "serhip_comm_create": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "serhip_allgather_rows": (c_int, [c_void_p, c_void_p, POINTER(c_int64), c_int32, c_void_p, c_void_p]),
+    "serhip_comm_destroy": (None, [c_void_p]),
     "serhip_profile_enable": (c_int, [c_void_p, c_int]),
     "serhip_profile_read": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
     "serhip_host_table": (c_int64, [c_int, c_int, c_int, POINTER(c_float), c_int64]),

@@ -4,6 +4,8 @@
 #include "../../include/serhip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is loaded with dlopen on first use
 
 #include <algorithm>
 #include <cstdio>
@@ -930,6 +932,123 @@ void serhip_plan_destroy(serhip_plan* plan) {
 }
 
 int serhip_plan_feature_dim(const serhip_plan* plan) { return plan ? plan->dim : SERHIP_E_INVALID; }
+
+// ---------------------------------------------------------------------------------------
+// RCCL fan-in of the feature shards (include/serhip.h: serhip_comm_*, serhip_allgather_rows)
+// ---------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string problem;
+};
+// a process that already holds an RCCL (torch's own copy) gets that one: dlopen by soname returns it
+const RcclApi* rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) {
+            a.problem = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "unknown error");
+            return a;
+        }
+        auto sym = [&](const char* n) {
+            void* p = dlsym(a.lib, n);
+            if (!p && a.problem.empty()) a.problem = std::string("RCCL symbol missing: ") + n;
+            return p;
+        };
+        a.get_unique_id = reinterpret_cast<decltype(a.get_unique_id)>(sym("ncclGetUniqueId"));
+        a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(sym("ncclCommInitRank"));
+        a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(sym("ncclCommDestroy"));
+        a.broadcast = reinterpret_cast<decltype(a.broadcast)>(sym("ncclBroadcast"));
+        a.group_start = reinterpret_cast<decltype(a.group_start)>(sym("ncclGroupStart"));
+        a.group_end = reinterpret_cast<decltype(a.group_end)>(sym("ncclGroupEnd"));
+        a.error_string = reinterpret_cast<decltype(a.error_string)>(sym("ncclGetErrorString"));
+        return a;
+    }();
+    return &api;
+}
+int rccl_fail(const char* what, ncclResult_t r) {
+    return fail(SERHIP_E_HIP, std::string(what) + ": " + rccl_api()->error_string(r));
+}
+}  // namespace
+
+struct serhip_comm {
+    ncclComm_t comm = nullptr;
+    int device = 0, rank = 0, world = 1;
+};
+
+int serhip_comm_unique_id(unsigned char* id_out) {
+    static_assert(sizeof(ncclUniqueId) == SERHIP_COMM_ID_BYTES, "SERHIP_COMM_ID_BYTES must be RCCL's id size");
+    if (!id_out) return fail(SERHIP_E_INVALID, "serhip_comm_unique_id: NULL argument");
+    const RcclApi& api = *rccl_api();
+    if (!api.problem.empty()) return fail(SERHIP_E_UNSUPPORTED, "serhip_comm_unique_id: " + api.problem);
+    ncclUniqueId id;
+    const ncclResult_t r = api.get_unique_id(&id);
+    if (r != ncclSuccess) return rccl_fail("serhip_comm_unique_id", r);
+    std::memcpy(id_out, &id, sizeof(id));
+    return SERHIP_OK;
+}
+
+int serhip_comm_create(serhip_ctx* ctx, const unsigned char* id, int rank, int world, serhip_comm** out) {
+    if (!ctx || !id || !out) return fail(SERHIP_E_INVALID, "serhip_comm_create: NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(SERHIP_E_INVALID, "serhip_comm_create: rank outside [0, world)");
+    const RcclApi& api = *rccl_api();
+    if (!api.problem.empty()) return fail(SERHIP_E_UNSUPPORTED, "serhip_comm_create: " + api.problem);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    auto* c = new serhip_comm;
+    c->device = ctx->device;
+    c->rank = rank;
+    c->world = world;
+    const ncclResult_t r = api.comm_init_rank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return rccl_fail("serhip_comm_create", r);
+    }
+    *out = c;
+    return SERHIP_OK;
+}
+
+int serhip_allgather_rows(serhip_comm* comm, const float* shard_dev, const int64_t* rows_per_rank, int32_t dim,
+                          float* out_dev, void* stream) {
+    if (!comm || !rows_per_rank || !out_dev) return fail(SERHIP_E_INVALID, "serhip_allgather_rows: NULL argument");
+    if (dim <= 0) return fail(SERHIP_E_INVALID, "serhip_allgather_rows: dim must be positive");
+    for (int r = 0; r < comm->world; ++r)
+        if (rows_per_rank[r] < 0) return fail(SERHIP_E_INVALID, "serhip_allgather_rows: negative row count");
+    if (rows_per_rank[comm->rank] > 0 && !shard_dev) return fail(SERHIP_E_INVALID, "serhip_allgather_rows: NULL shard");
+    const RcclApi& api = *rccl_api();
+    HIP_TRY(hipSetDevice(comm->device));
+    ncclResult_t r = api.group_start();
+    if (r != ncclSuccess) return rccl_fail("serhip_allgather_rows", r);
+    int64_t row = 0;
+    for (int root = 0; root < comm->world && r == ncclSuccess; ++root) {
+        const int64_t n = rows_per_rank[root];
+        if (n > 0)
+            r = api.broadcast(root == comm->rank ? shard_dev : out_dev + row * dim /* ignored off the root */, out_dev + row * dim, static_cast<size_t>(n) * dim,
+                              ncclFloat32, root, comm->comm, static_cast<hipStream_t>(stream));
+        row += n;
+    }
+    const ncclResult_t e = api.group_end();
+    if (r != ncclSuccess) return rccl_fail("serhip_allgather_rows", r);
+    if (e != ncclSuccess) return rccl_fail("serhip_allgather_rows", e);
+    return SERHIP_OK;
+}
+
+void serhip_comm_destroy(serhip_comm* comm) {
+    if (!comm) return;
+    if (comm->comm) (void)rccl_api()->comm_destroy(comm->comm);
+    delete comm;
+}
 
 int64_t serhip_frame_count(int64_t n_samples) {
     if (n_samples < 1) return SERHIP_E_INVALID;

@@ -6,6 +6,10 @@ The reference has no distributed code; its only fan-out is the ``multiprocessing
 over files of ``ser/_internal/data/data_loader.py:368-379``, which proves the units are
 independent (``imap_unordered``).  Segments never exchange data, so the gather is the
 single collective of the path.
+
+Two forms of that gather: :func:`all_gather_rows` on ``torch.distributed`` (backend ``nccl`` = RCCL; gloo in the
+CPU tests) and :class:`NativeRowGather` on the C ABI's own RCCL communicator (``serhip_comm_*``,
+``serhip_allgather_rows``) for hosts that do not run ``torch.distributed``.
 """
 
 from __future__ import annotations
@@ -81,3 +85,77 @@ def all_gather_rows(local, n_total: int, *, group=None):
         return full
     pieces = [full[r * per : r * per + int(bounds[r + 1] - bounds[r])] for r in range(world)]
     return torch.cat(pieces, dim=0)
+
+
+COMM_ID_BYTES = 128
+
+
+def new_comm_id() -> bytes:
+    """The opaque id of a new native communicator (``serhip_comm_unique_id``).  Rank 0 creates it and hands
+    the bytes to the other ranks by whatever transport the host has."""
+    import ctypes
+
+    from ._native import check, load_library
+
+    buf = (ctypes.c_ubyte * COMM_ID_BYTES)()
+    check(load_library().serhip_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class NativeRowGather:
+    """The fan-in of the feature shards on the C ABI's RCCL communicator: one instance per process / GPU.
+
+    ``NativeRowGather(comm_id, rank, world)`` is collective (every rank constructs it with the same id);
+    ``gather(local, rows_per_rank)`` returns the full ``[sum(rows_per_rank), D]`` float32 matrix on this
+    rank's GPU, shards in rank order (uneven and empty shards allowed), enqueued on torch's current stream.
+    """
+
+    def __init__(self, comm_id: bytes, rank: int, world: int, *, device_index: int | None = None) -> None:
+        import ctypes
+
+        from ._native import check, load_library
+        from .engine import get_engine
+
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError(f"comm_id must be {COMM_ID_BYTES} bytes")
+        self._lib = load_library()
+        self._engine = get_engine(device_index)
+        self.rank, self.world = int(rank), int(world)
+        handle = ctypes.c_void_p()
+        buf = (ctypes.c_ubyte * COMM_ID_BYTES).from_buffer_copy(comm_id)
+        check(self._lib.serhip_comm_create(self._engine._ctx.handle, buf, self.rank, self.world, ctypes.byref(handle)))
+        self._handle = handle
+
+    def gather(self, local, rows_per_rank):
+        import ctypes
+
+        import torch
+
+        from ._native import check
+
+        rows = np.ascontiguousarray(np.asarray(rows_per_rank, dtype=np.int64))
+        if rows.shape != (self.world,):
+            raise ValueError(f"rows_per_rank must have {self.world} entries")
+        if local.dtype != torch.float32 or local.dim() != 2 or int(local.shape[0]) != int(rows[self.rank]):
+            raise ValueError(f"rank {self.rank}: expected a float32 [{int(rows[self.rank])}, D] shard")
+        local = local.contiguous()
+        dim = int(local.shape[1])
+        full = torch.empty((int(rows.sum()), dim), dtype=torch.float32, device=local.device)
+        if full.numel() == 0:   # nothing to move on any rank (every rank sees the same rows_per_rank)
+            return full
+        stream = torch.cuda.current_stream(local.device).cuda_stream
+        check(self._lib.serhip_allgather_rows(
+            self._handle, ctypes.c_void_p(local.data_ptr()), rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+            dim, ctypes.c_void_p(full.data_ptr()), ctypes.c_void_p(stream)))
+        return full
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self._lib.serhip_comm_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self) -> None:  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass

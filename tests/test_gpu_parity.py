@@ -650,3 +650,40 @@ def test_against_committed_golden_vectors(engine, flags):
     np.testing.assert_allclose(tun, g["ragged_tuning"], atol=1e-6)
     assert_features_close(got, g["ragged_features"])
     np.testing.assert_allclose(log_mel_spectrogram(harmonic_clips(99, 2, 32000), 80), g["whisper_logmel80"], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_native_rccl_row_gather_world1():
+    """serhip_comm_* / serhip_allgather_rows through the C ABI on a one-rank communicator (the only size a
+    one-GPU box can form: RCCL refuses two ranks on one device).  The gathered matrix is the shard, in place in
+    the output buffer, on torch's current stream; argument errors come back as messages, not crashes."""
+    import torch
+
+    from ser_amd._native import SerhipError
+    from ser_amd.distributed import COMM_ID_BYTES, NativeRowGather, new_comm_id
+
+    comm_id = new_comm_id()
+    assert len(comm_id) == COMM_ID_BYTES and any(comm_id)
+    gather = NativeRowGather(comm_id, rank=0, world=1)
+    try:
+        local = torch.arange(5 * 187, dtype=torch.float32, device="cuda").reshape(5, 187) * 0.5
+        full = gather.gather(local, [5])
+        torch.cuda.synchronize()
+        assert full.data_ptr() != local.data_ptr()
+        assert torch.equal(full, local)
+        empty = gather.gather(local[:0], [0])
+        assert tuple(empty.shape) == (0, 187)
+        with pytest.raises(ValueError):
+            gather.gather(local, [4])
+        with pytest.raises(ValueError):
+            gather.gather(local, [5, 5])
+        import ctypes
+
+        from ser_amd._native import check, load_library
+        rows = (ctypes.c_int64 * 1)(-1)
+        with pytest.raises(SerhipError, match="negative row count"):
+            check(load_library().serhip_allgather_rows(gather._handle, None, rows, 187, ctypes.c_void_p(full.data_ptr()), None))
+    finally:
+        gather.close()
+    with pytest.raises(ValueError):
+        NativeRowGather(b"short", 0, 1)

@@ -178,3 +178,15 @@ def test_hand_counted_waits_touch_no_inflight_register():
     stores = [i for i, l in enumerate(body) if "global_store_dwordx4" in l]
     fewer = body[:stores[-1]] + body[stores[-1] + 1:]
     assert any("sure to follow the loads" in p for p in chk.check_kernel("fewer", fewer))
+
+
+def test_comm_entry_points_reject_bad_arguments_without_touching_rccl(native_lib):
+    """serhip_comm_* argument checks come before anything loads RCCL or touches a GPU."""
+    import ctypes
+
+    assert native_lib.serhip_comm_unique_id(None) == -1
+    assert b"NULL" in native_lib.serhip_last_error()
+    handle = ctypes.c_void_p()
+    assert native_lib.serhip_comm_create(None, None, 0, 1, ctypes.byref(handle)) == -1
+    assert native_lib.serhip_allgather_rows(None, None, None, 187, None, None) == -1
+    native_lib.serhip_comm_destroy(None)   # a no-op, like free(NULL)
