@@ -21,7 +21,9 @@ constants (nothing else) and follows only the feasible side of a branch whose co
 
 and checks that no instantiation uses scratch.  Run by tests/test_native_host.py (needs hipcc; no GPU).
 """
+import os
 import re
+import shlex
 import subprocess
 import sys
 import tempfile
@@ -37,7 +39,8 @@ def device_asm() -> str:
     with tempfile.TemporaryDirectory() as tmp:
         out = Path(tmp) / "serhip.s"
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S",
-                        "--cuda-device-only", "-o", str(out), str(ROOT / "ser_amd" / "csrc" / "serhip.hip")],
+                        "--cuda-device-only", *shlex.split(os.environ.get("SERHIP_CHECK_FLAGS", "")),   # e.g. -DSERHIP_EXP_...=1
+                        "-o", str(out), str(ROOT / "ser_amd" / "csrc" / "serhip.hip")],
                        check=True, capture_output=True)
         return out.read_text()
 

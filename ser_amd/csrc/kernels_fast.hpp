@@ -390,7 +390,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         const int fs = t * kHop - kNfft / 2;   // < 2^31: the host rejects longer segments
         const float* seg_audio = audio + sd.offset;
         if ((fs >= 0) & (fs + kNfft <= sd.len)) {
+#if SERHIP_EXP_K1_HOT_LOADS   // timing experiment: every interior frame reads the same 8 KB of its segment
+            const float* b0 = seg_audio + (fs & 0);
+#else
             const float* b0 = seg_audio + fs;
+#endif
             const float* b1 = b0 + 1024;       // immediate offsets reach 4 KiB
             const unsigned voff = 8u * static_cast<unsigned>(lane);
             load_pair_async<0>(dst[0], b0, voff);
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     // of the transform, so the next frame's samples are requested before it starts.
     int run_seg = -1;        // segment of the frames whose largest magnitude run_max holds (see finish_frame)
     unsigned run_max = 0;
-    auto finish_frame = [&, lane_outer = lane](size_t row, int seg, auto&& after_unpack) {
+    auto finish_frame = [&, lane_outer = lane](size_t row, int seg, auto&& request_next) {
 #if SERHIP_K1_OPAQUE_LANE
         // an opaque copy of the lane id: the addresses derived from it are recomputed per frame instead of
         // being hoisted out of the frame loop into ~40 VGPRs that the transform needs
@@ -527,6 +531,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         asm volatile("" : "+v"(lane));
 #else
         const int lane = lane_outer;
+#endif
+        // the transform's registers are free from here on: the next frame's samples are requested now, ahead of the
+        // unpack (1.2 % faster than behind it; SERHIP_EXP_K1_LOADS_AFTER_UNPACK: the earlier placement)
+#if !SERHIP_EXP_K1_LOADS_AFTER_UNPACK
+        request_next();
 #endif
         // ---- real-FFT unpack: bins k = lane + 64r and 1024 - k from Z[k], Z[1024-k]
         float mlo[8], mhi[8];
@@ -556,7 +565,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         }
         wave_lds_sync();  // every lane has read Z before the buffer is reused
         K1_STAMP(4)
-        after_unpack();
+#if SERHIP_EXP_K1_LOADS_AFTER_UNPACK
+        request_next();
+#endif
 
         // column maximum on the bit patterns: magnitudes are non-negative, so unsigned integer order is
         // float order and v_max3_u32 needs none of the NaN canonicalisation fmaxf drags in
