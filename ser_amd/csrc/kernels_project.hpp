@@ -21,8 +21,14 @@
 namespace serhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kProjTile = 32;   // frames per wave
-constexpr int kProjWaves = 3;   // waves per workgroup: one B row each to fetch; 96 frames = one 3 s clip
+// frames per wave: 32 (two 16-frame MFMA tiles, three waves per workgroup) or 16 (one tile, six waves; fewer registers
+// per wave, more waves per SIMD).  Either way a workgroup covers 96 frames = one 3 s clip and fetches each B row once.
+#ifndef SERHIP_K2_HALVES
+#define SERHIP_K2_HALVES 2
+#endif
+constexpr int kProjHalves = SERHIP_K2_HALVES;
+constexpr int kProjTile = 16 * kProjHalves;   // frames per wave
+constexpr int kProjWaves = 6 / kProjHalves;   // waves per workgroup; waves 0..2 fetch one B row each
 
 // v[l] (+|min) v[l ^ 16] and v[l ^ 32] in every lane without an LDS round trip: v_permlane16_swap /
 // v_permlane32_swap (gfx950) of two copies of v leave {rows 0,0,2,2 | rows 1,1,3,3} and {lower half twice | upper
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     // group, unconditionally: the waits in the loop are then exact vmcnt(n) counts and the prefetch holds.
     const size_t f0 = static_cast<size_t>(sd.stft_base) + (active ? t0 : blockIdx.x * kProjWaves * kProjTile);
     const float4* a0p = reinterpret_cast<const float4*>(sc.mags) + (f0 >> 4) * kTileF4 + i * 8 + kk;
-    const float4* a1p = (active && t0 + 16 < sd.n_stft) ? a0p + kTileF4 : a0p;
+    const float4* a1p = (kProjHalves == 2 && active && t0 + 16 < sd.n_stft) ? a0p + kTileF4 : a0p;
     const float4* cb = tb.chroma_b + (want_chroma ? static_cast<size_t>(sc.tuning_idx[blockIdx.y]) * kGroups * 64 : 0) + lane;
     const float4* mb = tb.mel_b + lane;
     float* mel_out = sc.mel + (static_cast<size_t>(sd.mel_base) + t0 + 4 * kk) * kMels + i;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     // what else is in the batch.
     auto retire = [&]() {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kProjHalves; ++h) {
             const int tb0 = t0 + 16 * h;
             if (tb0 < sd.n_stft) {   // wave-uniform
                 const f32x4 v = h ? lo1 : lo0;
@@ -180,12 +186,13 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     // fetch (an idle mel slot, chroma off) still loads a row some other wave of this group needs
     // -- never the shared all-zero row 0, which every workgroup on the chip would hammer in L2.
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int role = wave_s % 3;   // with six waves, waves 3..5 repeat the loads of 0..2 (L1 hits) and do not write s_b
     auto fetch_b = [&](int G, const int4& p) {
         const int live = want_mel ? p.z : 0;
         const float4* fallback = want_chroma ? cb + G * 64 : mb + static_cast<size_t>(max(p.x, p.y)) * 64;
         const float4* row = fallback;
-        if (wave_s == 1 && (live & 1)) row = mb + static_cast<size_t>(p.x) * 64;
-        if (wave_s == 2 && (live & 2)) row = mb + static_cast<size_t>(p.y) * 64;
+        if (role == 1 && (live & 1)) row = mb + static_cast<size_t>(p.x) * 64;
+        if (role == 2 && (live & 2)) row = mb + static_cast<size_t>(p.y) * 64;
         return *row;
     };
     // the per-group program, read as scalars (a vector load here would put a full vmcnt(0) wait, and
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
         if (want_chroma) {
             const float4 bc = sb[0];
             c0 = mfma4(a0, bc, c0);
-            c1 = mfma4(a1, bc, c1);
+            if constexpr (kProjHalves == 2) c1 = mfma4(a1, bc, c1);
         }
         if (want_mel) {
             const float4 p0 = float4{a0.x * a0.x, a0.y * a0.y, a0.z * a0.z, a0.w * a0.w};   // |X|^2 of the rounded |X|
@@ -210,12 +217,12 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
             if (p.z & 1) {   // wave-uniform
                 const float4 bl = sb[64];
                 lo0 = mfma4(p0, bl, lo0);
-                lo1 = mfma4(p1, bl, lo1);
+                if constexpr (kProjHalves == 2) lo1 = mfma4(p1, bl, lo1);
             }
             if (p.z & 2) {
                 const float4 bh = sb[128];
                 hi0 = mfma4(p0, bh, hi0);
-                hi1 = mfma4(p1, bh, hi1);
+                if constexpr (kProjHalves == 2) hi1 = mfma4(p1, bh, hi1);
             }
             for (int n = p.w; n > 0; --n) retire();
         }
@@ -227,12 +234,17 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     // they are the two halves of the same 128-byte lines, and requested back to back the second load
     // finds the lines the first one brought (a step apart it found them evicted: +17 % kernel time).
     for (int j = threadIdx.x; j < kGroups; j += kProjWaves * 64) s_prog[j] = tb.mel_prog[j];
-    float4 aE0 = load_mags(a0p), aE1 = load_mags(a1p), aO0 = load_mags(a0p + mags_group_offset(1)), aO1 = load_mags(a1p + mags_group_offset(1));
-    float4 aP0, aP1;
+    float4 aE0 = load_mags(a0p), aO0 = load_mags(a0p + mags_group_offset(1));
+    float4 aE1 = zero4, aO1 = zero4;
+    if constexpr (kProjHalves == 2) {
+        aE1 = load_mags(a1p);
+        aO1 = load_mags(a1p + mags_group_offset(1));
+    }
+    float4 aP0, aP1 = zero4;
     __syncthreads();
     float4 bE = fetch_b(0, prog_at(0));
     float4 bO = fetch_b(1, prog_at(1));
-    s_b[0][wave][lane] = bE;
+    if (wave_s < 3) s_b[0][wave][lane] = bE;
     __syncthreads();
 
     // one even + one odd step; the odd step consumes `ao*` and the even step refills `an*` (the other odd set)
@@ -240,17 +252,17 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
         // even group G: stage 0 holds its B rows
         bE = fetch_b(G + 2, prog_at(G + 2));            // G + 2 <= 64
         compute(G, aE0, aE1, prog_at(G));
-        s_b[1][wave][lane] = bO;                        // B rows of G + 1
+        if (wave_s < 3) s_b[1][wave][lane] = bO;        // B rows of G + 1
         aE0 = load_mags(a0p + mags_group_offset(G + 2));
-        aE1 = load_mags(a1p + mags_group_offset(G + 2));
+        if constexpr (kProjHalves == 2) aE1 = load_mags(a1p + mags_group_offset(G + 2));
         an0 = load_mags(a0p + mags_group_offset(G + 3));            // G + 3 = 65 at the end: the unused half of the last block
-        an1 = load_mags(a1p + mags_group_offset(G + 3));
+        if constexpr (kProjHalves == 2) an1 = load_mags(a1p + mags_group_offset(G + 3));
         __syncthreads();
         // odd group G + 1: stage 1
         const int G3 = min(G + 3, kGroups - 1);         // the last odd step fetches a B row nobody uses
         bO = fetch_b(G3, prog_at(G3));
         compute(G + 1, ao0, ao1, prog_at(G + 1));
-        s_b[0][wave][lane] = bE;                        // B rows of G + 2
+        if (wave_s < 3) s_b[0][wave][lane] = bE;        // B rows of G + 2
         __syncthreads();
     };
     static_assert((kGroups - 1) % 4 == 0, "the loop below takes four groups per trip");
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     if (want_chroma) {
         const float tiny = 1.17549435e-38f;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < kProjHalves; ++half) {
             const f32x4 c = half ? c1 : c0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
