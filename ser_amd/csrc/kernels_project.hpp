@@ -93,11 +93,31 @@ __device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 c) {
 // (PlanTables::mel_prog): which B rows the two slots use (row 0 is all zeros), which slots are live,
 // and how many blocks retire after the group.  All operands of group G + 1 are requested before the
 // MFMAs of group G are issued.
-__global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDesc* __restrict__ segs, PlanTables tb, Scratch sc) {
+// The per-group program travels as a kernel argument (1 KB by value): indexed by the wave-uniform group number it is
+// read with scalar loads from the kernarg segment -- no LDS copy, no v_readfirstlane, and nothing on the vector
+// memory counter that the software pipeline's waits count (-DSERHIP_K2_PROG_LDS=1: the first form, a copy in LDS).
+struct ProjProgram {
+    int4 g[kGroups];   // {row of slot lo, row of slot hi, live mask (1 lo, 2 hi), retires}
+};
+#ifndef SERHIP_K2_PROG_LDS
+#define SERHIP_K2_PROG_LDS 0
+#endif
+__global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDesc* __restrict__ segs, PlanTables tb, Scratch sc,
+                                                                    ProjProgram prog) {
     // B rows of the current and the next group, shared by the three waves (all work on one segment, so on
     // one tuning): [stage][0 chroma | 1 mel slot lo | 2 mel slot hi][lane]
+#ifndef SERHIP_K2_PAIR_STAGES
+#define SERHIP_K2_PAIR_STAGES 1   // LDS stage = the B rows of 2 groups, one barrier per pair (1); of 4 groups (2: measured equal); of 1 group (0: the first form)
+#endif
+#if SERHIP_K2_PAIR_STAGES
+    constexpr int kStageGroups = 2 * SERHIP_K2_PAIR_STAGES;
+    __shared__ float4 s_b[2][kStageGroups][3][64];   // [stage][group within the stage][row][lane]
+#else
     __shared__ float4 s_b[2][3][64];
+#endif
+#if SERHIP_K2_PROG_LDS
     __shared__ int4 s_prog[kGroups];
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const SegDesc sd = segs[blockIdx.y];
@@ -198,14 +218,22 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     // the per-group program, read as scalars (a vector load here would put a full vmcnt(0) wait, and
     // with it the end of all prefetching, into every iteration)
     auto prog_at = [&](int G) {
+#if SERHIP_K2_PROG_LDS
         const int4 v = s_prog[G];
         return int4{__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
                     __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w)};
+#else
+        return prog.g[G];
+#endif
     };
     // MFMAs of one group; B rows come from LDS stage G & 1
     auto compute = [&](int G, const float4& a0, const float4& a1, const int4& p) {
         if (!active) return;
+#if SERHIP_K2_PAIR_STAGES
+        const float4* sb = &s_b[(G / kStageGroups) & 1][G % kStageGroups][0][lane];
+#else
         const float4* sb = &s_b[G & 1][0][lane];
+#endif
         if (want_chroma) {
             const float4 bc = sb[0];
             c0 = mfma4(a0, bc, c0);
@@ -233,7 +261,9 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     // of G + 1 (requested a step ago) to LDS and then requests the A rows of BOTH groups G + 2 and G + 3:
     // they are the two halves of the same 128-byte lines, and requested back to back the second load
     // finds the lines the first one brought (a step apart it found them evicted: +17 % kernel time).
+#if SERHIP_K2_PROG_LDS
     for (int j = threadIdx.x; j < kGroups; j += kProjWaves * 64) s_prog[j] = tb.mel_prog[j];
+#endif
     float4 aE0 = load_mags(a0p), aO0 = load_mags(a0p + mags_group_offset(1));
     float4 aE1 = zero4, aO1 = zero4;
     if constexpr (kProjHalves == 2) {
@@ -241,9 +271,52 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
         aO1 = load_mags(a1p + mags_group_offset(1));
     }
     float4 aP0, aP1 = zero4;
+#if SERHIP_K2_PROG_LDS
     __syncthreads();
+#endif
     float4 bE = fetch_b(0, prog_at(0));
     float4 bO = fetch_b(1, prog_at(1));
+#if SERHIP_K2_PAIR_STAGES
+    if (wave_s < 3) {
+        s_b[0][0][wave][lane] = bE;
+        s_b[0][1][wave][lane] = bO;
+    }
+    if constexpr (kStageGroups == 4) {
+        bE = fetch_b(2, prog_at(2));
+        bO = fetch_b(3, prog_at(3));
+        if (wave_s < 3) {
+            s_b[0][2][wave][lane] = bE;
+            s_b[0][3][wave][lane] = bO;
+        }
+    }
+    __syncthreads();
+
+    // One step = the even group G and the odd group G + 1; an LDS stage holds the B rows of kStageGroups consecutive
+    // groups.  The step requests the B rows of the pair one stage ahead first, multiplies group G, requests the A
+    // rows of BOTH groups G + 2 and G + 3 (the two halves of the same 128-byte lines: requested back to back the
+    // second load finds the lines the first one brought; a step apart it found them evicted, +17 % kernel time),
+    // multiplies group G + 1 with the odd set loaded a step ago (`ao*`; the even step refills `an*`, the other odd
+    // set), and only then parks the new B rows in the other stage -- their loads have had two groups of MFMAs to
+    // land.  ONE barrier per stage: everybody finished reading the other stage before the previous barrier.
+    auto pair_step = [&](int G, const float4& ao0, const float4& ao1, float4& an0, float4& an1) {
+        const int Gb = G + kStageGroups;                // the pair that sits where this one does, one stage ahead
+        const int Gb0 = min(Gb, kGroups - 1), Gb1 = min(Gb + 1, kGroups - 1);   // past the end: rows nobody uses
+        bE = fetch_b(Gb0, prog_at(Gb0));
+        bO = fetch_b(Gb1, prog_at(Gb1));
+        compute(G, aE0, aE1, prog_at(G));
+        aE0 = load_mags(a0p + mags_group_offset(G + 2));
+        if constexpr (kProjHalves == 2) aE1 = load_mags(a1p + mags_group_offset(G + 2));
+        an0 = load_mags(a0p + mags_group_offset(G + 3));            // G + 3 = 65 at the end: the unused half of the last block
+        if constexpr (kProjHalves == 2) an1 = load_mags(a1p + mags_group_offset(G + 3));
+        compute(G + 1, ao0, ao1, prog_at(G + 1));
+        if (wave_s < 3) {
+            const int next = ((Gb / kStageGroups)) & 1;
+            s_b[next][Gb % kStageGroups][wave][lane] = bE;
+            s_b[next][Gb % kStageGroups + 1][wave][lane] = bO;
+        }
+        if ((G + 2) % kStageGroups == 0) __syncthreads();   // compile-time after inlining: the loop below passes G and G + 2
+    };
+#else
     if (wave_s < 3) s_b[0][wave][lane] = bE;
     __syncthreads();
 
@@ -265,6 +338,7 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
         if (wave_s < 3) s_b[0][wave][lane] = bE;        // B rows of G + 2
         __syncthreads();
     };
+#endif
     static_assert((kGroups - 1) % 4 == 0, "the loop below takes four groups per trip");
 #pragma unroll 1
     for (int G = 0; G < kGroups - 1; G += 4) {

@@ -232,6 +232,7 @@ struct serhip_plan {
     int dim = 0;
     void* dev_blob = nullptr;    // one allocation holding every table
     PlanTables tb{};
+    ProjProgram proj_prog{};     // host copy of the per-group program: a kernel argument of k_project_frames
     int peak_cap = 0;
 };
 
@@ -592,7 +593,7 @@ int launch_chunks(serhip_plan* plan, const CallPlan& cp, const Placement& pl, ch
                 LaunchTimer lt(ctx, SERHIP_KERNEL_PROJECT_FRAMES, stream, timed);
                 hipLaunchKernelGGL(k_project_frames, dim3((tiles + kProjWaves - 1) / kProjWaves, static_cast<unsigned>(c.count)),
                                    dim3(kProjWaves * 64), 0,
-                                   stream, dd, plan->tb, sf);
+                                   stream, dd, plan->tb, sf, plan->proj_prog);
             }
             {
                 LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream, timed);
@@ -898,6 +899,7 @@ int serhip_plan_fast(serhip_ctx* ctx, int sample_rate, uint32_t feature_flags, s
     tb.mel_b = reinterpret_cast<const float4*>(d + o_melb);
     tb.chroma_b = reinterpret_cast<const float4*>(d + o_chroma);
     tb.mel_prog = reinterpret_cast<const int4*>(d + o_blk);
+    std::memcpy(plan->proj_prog.g, prog, sizeof(prog));
     tb.dct = reinterpret_cast<const float*>(d + o_dct);
     tb.edges = reinterpret_cast<const double*>(d + o_edges);
     tb.mel_f = reinterpret_cast<const double*>(d + o_melf);
