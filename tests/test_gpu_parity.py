@@ -201,6 +201,13 @@ def test_top_db_clipping_paths(engine, flags):
     # the same clips one by one and in the reverse order: stale dB rows of other calls must never be read
     back, _ = gpu_rows(engine, flags, audio, offs[::-1], lens)
     np.testing.assert_array_equal(back[::-1], got)
+    # without chroma the segment's magnitude bound takes another route (no tuning kernel to reduce it: per-wave
+    # running maxima and atomics in the FFT kernel); the clipped MFCC / mel blocks must come out the same
+    from ser_amd import FeatureFlags
+
+    no_chroma = FeatureFlags(mfcc=True, chroma=False, mel=True, contrast=False, tonnetz=False)
+    part = engine.features(audio, offs, lens, SR, no_chroma).cpu().numpy()
+    np.testing.assert_array_equal(part, np.concatenate([got[:, MFCC], got[:, MEL]], axis=1))
 
 
 def test_more_segments_than_one_launch_holds(engine, flags):
