@@ -21,14 +21,17 @@
 namespace serhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// frames per wave: 32 (two 16-frame MFMA tiles, three waves per workgroup) or 16 (one tile, six waves; fewer registers
-// per wave, more waves per SIMD).  Either way a workgroup covers 96 frames = one 3 s clip and fetches each B row once.
+// 16-frame MFMA tiles per wave (SERHIP_K2_HALVES): 2 = 32 frames per wave, three waves per workgroup (the default);
+// 1 = six waves of one tile (fewer registers, more waves per SIMD: measured 18 % slower); 3 = two waves of three tiles.
+// Either way a workgroup covers 96 frames = one 3 s clip and fetches each B row once.
 #ifndef SERHIP_K2_HALVES
 #define SERHIP_K2_HALVES 2
 #endif
 constexpr int kProjHalves = SERHIP_K2_HALVES;
+static_assert(kProjHalves >= 1 && kProjHalves <= 3, "one to three tiles per wave");
 constexpr int kProjTile = 16 * kProjHalves;   // frames per wave
-constexpr int kProjWaves = 6 / kProjHalves;   // waves per workgroup; waves 0..2 fetch one B row each
+constexpr int kProjWaves = 6 / kProjHalves;   // waves per workgroup
+constexpr int kProjBLoads = (3 + kProjWaves - 1) / kProjWaves;   // B rows a wave fetches per group: 1, or 2 with two waves
 
 // v[l] (+|min) v[l ^ 16] and v[l ^ 32] in every lane without an LDS round trip: v_permlane16_swap /
 // v_permlane32_swap (gfx950) of two copies of v leave {rows 0,0,2,2 | rows 1,1,3,3} and {lower half twice | upper
@@ -95,53 +98,41 @@ __device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 c) {
 // MFMAs of group G are issued.
 // The per-group program travels as a kernel argument (1 KB by value): indexed by the wave-uniform group number it is
 // read with scalar loads from the kernarg segment -- no LDS copy, no v_readfirstlane, and nothing on the vector
-// memory counter that the software pipeline's waits count (-DSERHIP_K2_PROG_LDS=1: the first form, a copy in LDS).
+// memory counter that the software pipeline's waits count (the first form kept a copy in LDS: +1.8 %).
 struct ProjProgram {
     int4 g[kGroups];   // {row of slot lo, row of slot hi, live mask (1 lo, 2 hi), retires}
 };
-#ifndef SERHIP_K2_PROG_LDS
-#define SERHIP_K2_PROG_LDS 0
-#endif
 __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDesc* __restrict__ segs, PlanTables tb, Scratch sc,
                                                                     ProjProgram prog) {
-    // B rows of the current and the next group, shared by the three waves (all work on one segment, so on
-    // one tuning): [stage][0 chroma | 1 mel slot lo | 2 mel slot hi][lane]
-#ifndef SERHIP_K2_PAIR_STAGES
-#define SERHIP_K2_PAIR_STAGES 1   // LDS stage = the B rows of 2 groups, one barrier per pair (1); of 4 groups (2: measured equal); of 1 group (0: the first form)
-#endif
-#if SERHIP_K2_PAIR_STAGES
-    constexpr int kStageGroups = 2 * SERHIP_K2_PAIR_STAGES;
-    __shared__ float4 s_b[2][kStageGroups][3][64];   // [stage][group within the stage][row][lane]
-#else
-    __shared__ float4 s_b[2][3][64];
-#endif
-#if SERHIP_K2_PROG_LDS
-    __shared__ int4 s_prog[kGroups];
-#endif
+    // B rows, shared by the workgroup's waves (all work on one segment, so on one tuning).  A stage holds the rows of
+    // a PAIR of groups: [stage][group parity][0 chroma | 1 mel slot lo | 2 mel slot hi][lane]
+    __shared__ float4 s_b[2][2][3][64];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const SegDesc sd = segs[blockIdx.y];
     if (blockIdx.x * kProjWaves * kProjTile >= sd.n_stft) return;   // whole workgroup
     const int t0 = (blockIdx.x * kProjWaves + wave) * kProjTile;
     const bool active = t0 < sd.n_stft;   // a wave without a tile still fetches B rows and joins the barriers
     const bool want_chroma = (tb.flags & 2u) != 0, want_mel = (tb.flags & 5u) != 0;
     const int i = lane & 15, kk = lane >> 4;
-    // A operands: the two 16-frame tiles of this wave; group G of a tile starts at float4 index
+    // A operands: the 16-frame tiles of this wave; group G of a tile starts at float4 index
     // mags_group_offset(G) and lane (frame i, kk) takes float4 i*8 + kk from there: an even group and the
     // odd one after it are the two halves of the same sixteen 128-byte lines (see mags_tile_index).  Frame
     // slots past the segment's end inside a tile were never written: their rows of C are garbage and are
-    // not stored.  A second tile that lies wholly past the end is replaced by the first; a wave without a
-    // tile reads the workgroup's first tile and discards it.  Every wave issues the same three loads per
+    // not stored.  A tile that lies wholly past the end is replaced by the first; a wave without a
+    // tile reads the workgroup's first tile and discards it.  Every wave issues the same loads per
     // group, unconditionally: the waits in the loop are then exact vmcnt(n) counts and the prefetch holds.
     const size_t f0 = static_cast<size_t>(sd.stft_base) + (active ? t0 : blockIdx.x * kProjWaves * kProjTile);
-    const float4* a0p = reinterpret_cast<const float4*>(sc.mags) + (f0 >> 4) * kTileF4 + i * 8 + kk;
-    const float4* a1p = (kProjHalves == 2 && active && t0 + 16 < sd.n_stft) ? a0p + kTileF4 : a0p;
+    const float4* ap[kProjHalves];
+    ap[0] = reinterpret_cast<const float4*>(sc.mags) + (f0 >> 4) * kTileF4 + i * 8 + kk;
+#pragma unroll
+    for (int h = 1; h < kProjHalves; ++h) ap[h] = (active && t0 + 16 * h < sd.n_stft) ? ap[0] + h * kTileF4 : ap[0];
     const float4* cb = tb.chroma_b + (want_chroma ? static_cast<size_t>(sc.tuning_idx[blockIdx.y]) * kGroups * 64 : 0) + lane;
     const float4* mb = tb.mel_b + lane;
     float* mel_out = sc.mel + (static_cast<size_t>(sd.mel_base) + t0 + 4 * kk) * kMels + i;
 
     // top_db clips dB values more than 80 below the segment's maximum.  That maximum is at most
-    // 10 log10(cmax^2 * mel_wsum_max) (cmax: the segment's largest |X|, from k_stft_frames), so a block
+    // 10 log10(cmax^2 * mel_wsum_max) (cmax: a bound of the segment's largest |X|, from k_stft_frames), so a block
     // of dB values that all lie within 80 dB of this bound can never be clipped: k_segment_finish<2> will
     // take the tile's sum as it is and the rows need not be written.  The 0.01 dB cover the rounding of
     // the f32 sums and of log10f (< 3e-4 dB).
@@ -149,12 +140,13 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     const float store_below = 10.0f * log10f(fmaxf(1e-10f, cmax * cmax * tb.mel_wsum_max)) + 0.01f - 80.0f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
-    f32x4 c0 = zero, c1 = zero;
-    f32x4 lo0 = zero, lo1 = zero, hi0 = zero, hi1 = zero;
+    f32x4 c[kProjHalves], lo[kProjHalves], hi[kProjHalves];
+#pragma unroll
+    for (int h = 0; h < kProjHalves; ++h) c[h] = lo[h] = hi[h] = zero;
     int cur = 0;   // block held by slot lo
 
     // Retire slot lo (block cur).  C layout: column j = lane & 15 (filter), rows 4*kk + r (frames).  Per
-    // 16-frame half tile it leaves what k_segment_finish<2> reduces: the power in dB per frame
+    // 16-frame tile it leaves what k_segment_finish<2> reduces: the power in dB per frame
     // (power_to_db of mfcc, dsp.py:108), the power summed over the tile's frames (mel mean) and the
     // tile's largest dB value (top_db reference).  Sums run in a fixed order: results do not depend on
     // what else is in the batch.
@@ -163,7 +155,7 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
         for (int h = 0; h < kProjHalves; ++h) {
             const int tb0 = t0 + 16 * h;
             if (tb0 < sd.n_stft) {   // wave-uniform
-                const f32x4 v = h ? lo1 : lo0;
+                const f32x4 v = lo[h];
                 float psum = 0.0f, dmax = -INFINITY, dmin = INFINITY;
                 double dsum = 0.0;
                 float db[4];
@@ -197,158 +189,116 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
                 if (lane == 0) sc.mel_dbmax[tile * 8 + cur] = dmax;
             }
         }
-        lo0 = hi0;
-        lo1 = hi1;
-        hi0 = hi1 = zero;
+#pragma unroll
+        for (int h = 0; h < kProjHalves; ++h) {
+            lo[h] = hi[h];
+            hi[h] = zero;
+        }
         ++cur;
     };
-    // wave w fetches B row w of a group (0 chroma, 1 mel slot lo, 2 mel slot hi).  A wave with nothing to
-    // fetch (an idle mel slot, chroma off) still loads a row some other wave of this group needs
-    // -- never the shared all-zero row 0, which every workgroup on the chip would hammer in L2.
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const int role = wave_s % 3;   // with six waves, waves 3..5 repeat the loads of 0..2 (L1 hits) and do not write s_b
-    auto fetch_b = [&](int G, const int4& p) {
+    // B rows of a group: 0 chroma, 1 mel slot lo, 2 mel slot hi.  Load j of wave w fetches row w + j * kProjWaves;
+    // a wave with nothing to fetch there (no such row, an idle mel slot, chroma off) still loads a row some other
+    // wave of this group needs (an L1 hit) -- never the shared all-zero row 0, which every workgroup on the chip
+    // would hammer in L2 -- so that every wave issues the same number of loads.
+    auto fetch_b = [&](int G, const int4& p, int j) {
+        const int row_id = wave + j * kProjWaves;
         const int live = want_mel ? p.z : 0;
-        const float4* fallback = want_chroma ? cb + G * 64 : mb + static_cast<size_t>(max(p.x, p.y)) * 64;
-        const float4* row = fallback;
-        if (role == 1 && (live & 1)) row = mb + static_cast<size_t>(p.x) * 64;
-        if (role == 2 && (live & 2)) row = mb + static_cast<size_t>(p.y) * 64;
+        const float4* row = want_chroma ? cb + G * 64 : mb + static_cast<size_t>(max(p.x, p.y)) * 64;
+        if (row_id == 1 && (live & 1)) row = mb + static_cast<size_t>(p.x) * 64;
+        if (row_id == 2 && (live & 2)) row = mb + static_cast<size_t>(p.y) * 64;
         return *row;
     };
-    // the per-group program, read as scalars (a vector load here would put a full vmcnt(0) wait, and
-    // with it the end of all prefetching, into every iteration)
-    auto prog_at = [&](int G) {
-#if SERHIP_K2_PROG_LDS
-        const int4 v = s_prog[G];
-        return int4{__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
-                    __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w)};
-#else
-        return prog.g[G];
-#endif
+    // park the fetched rows of a group in LDS (row ids past 2 are the duplicates above)
+    auto park_b = [&](float4 (*stage_group)[64], const float4 (&b)[kProjBLoads]) {
+#pragma unroll
+        for (int j = 0; j < kProjBLoads; ++j)
+            if (wave + j * kProjWaves < 3) stage_group[wave + j * kProjWaves][lane] = b[j];
     };
-    // MFMAs of one group; B rows come from LDS stage G & 1
-    auto compute = [&](int G, const float4& a0, const float4& a1, const int4& p) {
+    auto prog_at = [&](int G) { return prog.g[G]; };   // scalar loads (G is wave-uniform)
+    // MFMAs of one group; its B rows sit in stage (G / 2) & 1, slot G & 1
+    auto compute = [&](int G, const float4 (&a)[kProjHalves], const int4& p) {
         if (!active) return;
-#if SERHIP_K2_PAIR_STAGES
-        const float4* sb = &s_b[(G / kStageGroups) & 1][G % kStageGroups][0][lane];
-#else
-        const float4* sb = &s_b[G & 1][0][lane];
-#endif
+        const float4* sb = &s_b[(G >> 1) & 1][G & 1][0][lane];
         if (want_chroma) {
             const float4 bc = sb[0];
-            c0 = mfma4(a0, bc, c0);
-            if constexpr (kProjHalves == 2) c1 = mfma4(a1, bc, c1);
+#pragma unroll
+            for (int h = 0; h < kProjHalves; ++h) c[h] = mfma4(a[h], bc, c[h]);
         }
         if (want_mel) {
-            const float4 p0 = float4{a0.x * a0.x, a0.y * a0.y, a0.z * a0.z, a0.w * a0.w};   // |X|^2 of the rounded |X|
-            const float4 p1 = float4{a1.x * a1.x, a1.y * a1.y, a1.z * a1.z, a1.w * a1.w};
+            float4 pw[kProjHalves];   // |X|^2 of the rounded |X|
+#pragma unroll
+            for (int h = 0; h < kProjHalves; ++h) pw[h] = float4{a[h].x * a[h].x, a[h].y * a[h].y, a[h].z * a[h].z, a[h].w * a[h].w};
             if (p.z & 1) {   // wave-uniform
                 const float4 bl = sb[64];
-                lo0 = mfma4(p0, bl, lo0);
-                if constexpr (kProjHalves == 2) lo1 = mfma4(p1, bl, lo1);
+#pragma unroll
+                for (int h = 0; h < kProjHalves; ++h) lo[h] = mfma4(pw[h], bl, lo[h]);
             }
             if (p.z & 2) {
                 const float4 bh = sb[128];
-                hi0 = mfma4(p0, bh, hi0);
-                if constexpr (kProjHalves == 2) hi1 = mfma4(p1, bh, hi1);
+#pragma unroll
+                for (int h = 0; h < kProjHalves; ++h) hi[h] = mfma4(pw[h], bh, hi[h]);
             }
             for (int n = p.w; n > 0; --n) retire();
         }
     };
-
-    // Software pipeline over register sets, no register copies: E for even groups, O and P alternately
-    // for odd groups.  The even step G requests the B row of G + 2, multiplies group G, stores the B row
-    // of G + 1 (requested a step ago) to LDS and then requests the A rows of BOTH groups G + 2 and G + 3:
-    // they are the two halves of the same 128-byte lines, and requested back to back the second load
-    // finds the lines the first one brought (a step apart it found them evicted: +17 % kernel time).
-#if SERHIP_K2_PROG_LDS
-    for (int j = threadIdx.x; j < kGroups; j += kProjWaves * 64) s_prog[j] = tb.mel_prog[j];
-#endif
-    float4 aE0 = load_mags(a0p), aO0 = load_mags(a0p + mags_group_offset(1));
-    float4 aE1 = zero4, aO1 = zero4;
-    if constexpr (kProjHalves == 2) {
-        aE1 = load_mags(a1p);
-        aO1 = load_mags(a1p + mags_group_offset(1));
-    }
-    float4 aP0, aP1 = zero4;
-#if SERHIP_K2_PROG_LDS
-    __syncthreads();
-#endif
-    float4 bE = fetch_b(0, prog_at(0));
-    float4 bO = fetch_b(1, prog_at(1));
-#if SERHIP_K2_PAIR_STAGES
-    if (wave_s < 3) {
-        s_b[0][0][wave][lane] = bE;
-        s_b[0][1][wave][lane] = bO;
-    }
-    if constexpr (kStageGroups == 4) {
-        bE = fetch_b(2, prog_at(2));
-        bO = fetch_b(3, prog_at(3));
-        if (wave_s < 3) {
-            s_b[0][2][wave][lane] = bE;
-            s_b[0][3][wave][lane] = bO;
-        }
-    }
-    __syncthreads();
-
-    // One step = the even group G and the odd group G + 1; an LDS stage holds the B rows of kStageGroups consecutive
-    // groups.  The step requests the B rows of the pair one stage ahead first, multiplies group G, requests the A
-    // rows of BOTH groups G + 2 and G + 3 (the two halves of the same 128-byte lines: requested back to back the
-    // second load finds the lines the first one brought; a step apart it found them evicted, +17 % kernel time),
-    // multiplies group G + 1 with the odd set loaded a step ago (`ao*`; the even step refills `an*`, the other odd
-    // set), and only then parks the new B rows in the other stage -- their loads have had two groups of MFMAs to
-    // land.  ONE barrier per stage: everybody finished reading the other stage before the previous barrier.
-    auto pair_step = [&](int G, const float4& ao0, const float4& ao1, float4& an0, float4& an1) {
-        const int Gb = G + kStageGroups;                // the pair that sits where this one does, one stage ahead
-        const int Gb0 = min(Gb, kGroups - 1), Gb1 = min(Gb + 1, kGroups - 1);   // past the end: rows nobody uses
-        bE = fetch_b(Gb0, prog_at(Gb0));
-        bO = fetch_b(Gb1, prog_at(Gb1));
-        compute(G, aE0, aE1, prog_at(G));
-        aE0 = load_mags(a0p + mags_group_offset(G + 2));
-        if constexpr (kProjHalves == 2) aE1 = load_mags(a1p + mags_group_offset(G + 2));
-        an0 = load_mags(a0p + mags_group_offset(G + 3));            // G + 3 = 65 at the end: the unused half of the last block
-        if constexpr (kProjHalves == 2) an1 = load_mags(a1p + mags_group_offset(G + 3));
-        compute(G + 1, ao0, ao1, prog_at(G + 1));
-        if (wave_s < 3) {
-            const int next = ((Gb / kStageGroups)) & 1;
-            s_b[next][Gb % kStageGroups][wave][lane] = bE;
-            s_b[next][Gb % kStageGroups + 1][wave][lane] = bO;
-        }
-        if ((G + 2) % kStageGroups == 0) __syncthreads();   // compile-time after inlining: the loop below passes G and G + 2
+    auto load_a = [&](float4 (&dst)[kProjHalves], int G) {
+#pragma unroll
+        for (int h = 0; h < kProjHalves; ++h) dst[h] = load_mags(ap[h] + mags_group_offset(G));
     };
-#else
-    if (wave_s < 3) s_b[0][wave][lane] = bE;
+
+    // Software pipeline over register sets, no register copies: E for even groups, O and P alternately for odd groups.
+    float4 aE[kProjHalves], aO[kProjHalves], aP[kProjHalves];
+    load_a(aE, 0);
+    load_a(aO, 1);
+#pragma unroll
+    for (int h = 0; h < kProjHalves; ++h) aP[h] = zero4;
+    float4 bE[kProjBLoads], bO[kProjBLoads];
+#pragma unroll
+    for (int j = 0; j < kProjBLoads; ++j) {
+        bE[j] = fetch_b(0, prog_at(0), j);
+        bO[j] = fetch_b(1, prog_at(1), j);
+    }
+    park_b(s_b[0][0], bE);
+    park_b(s_b[0][1], bO);
     __syncthreads();
 
-    // one even + one odd step; the odd step consumes `ao*` and the even step refills `an*` (the other odd set)
-    auto pair_step = [&](int G, const float4& ao0, const float4& ao1, float4& an0, float4& an1) {
-        // even group G: stage 0 holds its B rows
-        bE = fetch_b(G + 2, prog_at(G + 2));            // G + 2 <= 64
-        compute(G, aE0, aE1, prog_at(G));
-        if (wave_s < 3) s_b[1][wave][lane] = bO;        // B rows of G + 1
-        aE0 = load_mags(a0p + mags_group_offset(G + 2));
-        if constexpr (kProjHalves == 2) aE1 = load_mags(a1p + mags_group_offset(G + 2));
-        an0 = load_mags(a0p + mags_group_offset(G + 3));            // G + 3 = 65 at the end: the unused half of the last block
-        if constexpr (kProjHalves == 2) an1 = load_mags(a1p + mags_group_offset(G + 3));
-        __syncthreads();
-        // odd group G + 1: stage 1
-        const int G3 = min(G + 3, kGroups - 1);         // the last odd step fetches a B row nobody uses
-        bO = fetch_b(G3, prog_at(G3));
-        compute(G + 1, ao0, ao1, prog_at(G + 1));
-        if (wave_s < 3) s_b[0][wave][lane] = bE;        // B rows of G + 2
+    // One step = the even group G and the odd group G + 1, whose B rows sit in stage (G / 2) & 1.  The step requests
+    // the B rows of the next pair first, multiplies group G, requests the A rows of BOTH groups G + 2 and G + 3 (the
+    // two halves of the same 128-byte lines: requested back to back the second load finds the lines the first one
+    // brought; a step apart it found them evicted, +17 % kernel time), multiplies group G + 1 with the odd set loaded
+    // a step ago (`ao`; the even step refills `an`, the other odd set), and only then parks the new B rows in the
+    // other stage -- their loads have had two groups of MFMAs to land -- behind ONE barrier per pair (per group in
+    // the first form: +1.6 %; per four groups: equal): everybody finished reading that stage before the previous
+    // step's barrier.
+    auto pair_step = [&](int G, const float4 (&ao)[kProjHalves], float4 (&an)[kProjHalves]) {
+        const int G3 = min(G + 3, kGroups - 1);         // the last step fetches a B row nobody uses
+#pragma unroll
+        for (int j = 0; j < kProjBLoads; ++j) {
+            bE[j] = fetch_b(G + 2, prog_at(G + 2), j);  // G + 2 <= 64
+            bO[j] = fetch_b(G3, prog_at(G3), j);
+        }
+        compute(G, aE, prog_at(G));
+        load_a(aE, G + 2);
+        load_a(an, G + 3);                              // G + 3 = 65 at the end: the unused half of the last block
+        compute(G + 1, ao, prog_at(G + 1));
+        const int next = ((G >> 1) + 1) & 1;
+        park_b(s_b[next][0], bE);
+        park_b(s_b[next][1], bO);
         __syncthreads();
     };
-#endif
     static_assert((kGroups - 1) % 4 == 0, "the loop below takes four groups per trip");
 #pragma unroll 1
     for (int G = 0; G < kGroups - 1; G += 4) {
-        pair_step(G, aO0, aO1, aP0, aP1);
-        pair_step(G + 2, aP0, aP1, aO0, aO1);
+        pair_step(G, aO, aP);
+        pair_step(G + 2, aP, aO);
     }
     // group 64 (kGroups is odd) holds only bin 1024 and three zero pads, in the kk = 0 chunk; the other
     // chunks of that group were never written
-    if (kk != 0) aE0 = aE1 = zero4;
-    compute(kGroups - 1, aE0, aE1, prog_at(kGroups - 1));
+    if (kk != 0) {
+#pragma unroll
+        for (int h = 0; h < kProjHalves; ++h) aE[h] = zero4;
+    }
+    compute(kGroups - 1, aE, prog_at(kGroups - 1));
     if (active && want_mel)
         while (cur < 8) retire();
     if (!active) return;
@@ -358,11 +308,11 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
         const float tiny = 1.17549435e-38f;
 #pragma unroll
         for (int half = 0; half < kProjHalves; ++half) {
-            const f32x4 c = half ? c1 : c0;
+            const f32x4 cc = c[half];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = t0 + 16 * half + 4 * kk + r;
-                const float raw = c[r];
+                const float raw = cc[r];
                 float mx = row_max(fabsf(raw));
                 if (mx < tiny) mx = 1.0f;
                 if (t < sd.n_stft) sc.chroma_norm[(static_cast<size_t>(sd.stft_base) + t) * 16 + i] = raw / mx;
