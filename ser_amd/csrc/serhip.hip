@@ -552,7 +552,8 @@ int launch_chunks(serhip_plan* plan, const CallPlan& cp, const Placement& pl, ch
     for (const Chunk& c : cp.chunks) {
         const SegDesc* dd = d_descs + c.first;
         if (!c.generic) {
-            HIP_TRY(hipMemsetAsync(sf.seg_cmax, 0, static_cast<size_t>(c.count) * sizeof(unsigned), stream));
+            // the atomicMax route of the segment maximum starts from zero; with chroma on k_segment_finish<1> stores it
+            if (!want_chroma) HIP_TRY(hipMemsetAsync(sf.seg_cmax, 0, static_cast<size_t>(c.count) * sizeof(unsigned), stream));
             {
                 LaunchTimer lt(ctx, SERHIP_KERNEL_STFT_FRAMES, stream, timed);
                 auto* k1 = want_proj ? (want_chroma ? k_stft_frames<true, true> : k_stft_frames<true, false>)
