@@ -24,6 +24,14 @@
 
 namespace serhip {
 
+// Build switches of this header.  All default to the shipped form; none is set by __graft_entry__.build().
+//   SERHIP_K1_WAVES, SERHIP_K1_OPAQUE_LANE, SERHIP_K1_OPAQUE_LOAD, SERHIP_K1_WAIT_FENCED   tuning parameters (below)
+//   SERHIP_K1_STAMPS=1                    diagnostic build: per-phase cycle sums
+//   SERHIP_EXP_K1_*=1                     the A/B and timing-only variants behind DESIGN.md's table of k_stft_frames
+//                                         variants (scripts/experiments/ab_bench.sh builds them next to the shipped
+//                                         library): PLAIN_STORES, PEAKS_ALL_LANES, CMAX_PER_FRAME and
+//                                         LOADS_AFTER_UNPACK restore the form a row replaced (results identical);
+//                                         HOT_STORES, HOT_LOADS and ST34 are timing-only (results are garbage).
 #ifndef SERHIP_K1_WAVES
 #define SERHIP_K1_WAVES 16
 #endif
