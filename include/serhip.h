@@ -95,7 +95,10 @@ int serhip_fast_features(serhip_plan* plan, const float* audio_dev, int64_t n_au
                          float* out_dev, float* tuning_dev, void* stream);
 
 /* serhip_fast_features for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists
- * for code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same
+ * for tight serving loops, real-time threads and harnesses that forbid hipMalloc.  It is NOT capturable:
+ * do not call it on a stream that is under HIP graph capture -- every call uploads its descriptors from
+ * one reused pinned staging buffer (a replayed graph would upload whatever the last call left there) and,
+ * from the second call on, waits on the host for the previous upload's event.  Same
  * arguments, same kernels and bit-identical results as serhip_fast_features, but every byte of scratch
  * (descriptors, work units, magnitudes, peaks, partial sums) lives in a file-scope `static __device__`
  * array of SERHIP_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds from code-object load
@@ -195,7 +198,8 @@ int serhip_mlp_predict(serhip_ctx* ctx, const void* x_dev, int x_is_f64, int64_t
  *   serhip_allgather_rows   out_dev[sum(rows_per_rank), dim] = the shards [rows_per_rank[r], dim] of all ranks in
  *                           rank order, on every rank; rows_per_rank is a HOST array [world] (shards may differ in
  *                           size, and may be empty); shard_dev holds this rank's rows_per_rank[rank] rows.
- *                           Enqueued on `stream` (one grouped RCCL call: a broadcast per non-empty shard). */
+ *                           Enqueued on `stream`: ONE ncclAllGather when all shards have the same non-zero row
+ *                           count, otherwise one grouped call of a broadcast per non-empty shard. */
 #define SERHIP_COMM_ID_BYTES 128
 typedef struct serhip_comm serhip_comm;
 int serhip_comm_unique_id(unsigned char* id_out);
@@ -225,7 +229,8 @@ int serhip_profile_read(serhip_ctx* ctx, int kind, double* total_ms, int64_t* la
  * drive the discrete decisions (even-count median, ties, empty sets, more peaks than fit in LDS) with
  * hand-derived answers.  Synchronous; all pointers are HOST pointers.
  *   pitch_mag     [sum(frame_counts)][2] float32 (pitch in Hz, magnitude), frame after frame
- *   frame_counts  [n_frames] peaks per STFT frame
+ *   frame_counts  [n_frames] peaks per STFT frame, each 0..1023 (the count field of the scratch word);
+ *                 n_frames x max(count) is bounded at 2^24 peak slots
  *   tuning_out    one float32: the estimate in fractions of a semitone, in [-0.5, 0.5) */
 int serhip_tuning_from_peaks(serhip_plan* plan, const float* pitch_mag, const int32_t* frame_counts,
                              int32_t n_frames, float* tuning_out);

@@ -39,8 +39,8 @@ def device_asm() -> str:
     with tempfile.TemporaryDirectory() as tmp:
         out = Path(tmp) / "serhip.s"
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S",
-                        "--cuda-device-only", *shlex.split(os.environ.get("SERHIP_CHECK_FLAGS", "")),   # e.g. -DSERHIP_EXP_...=1
-                        "-o", str(out), str(ROOT / "ser_amd" / "csrc" / "serhip.hip")],
+                        "--cuda-device-only", *shlex.split(os.environ.get("SERHIP_CHECK_FLAGS", "")),   # e.g. -DSERHIP_EXP_...=1 with SERHIP_CHECK_SOURCE=<patched copy>/serhip.hip
+                        "-o", str(out), os.environ.get("SERHIP_CHECK_SOURCE", str(ROOT / "ser_amd" / "csrc" / "serhip.hip"))],
                        check=True, capture_output=True)
         return out.read_text()
 

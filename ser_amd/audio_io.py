@@ -3,8 +3,9 @@
 Behaviour of ``read_audio_file`` / ``_prepare_audio_buffer``
 (``ser/_internal/utils/audio_utils.py:28-162``): native sample rate (never
 resampled), NaN/inf scrubbed to 0, channel mean in float32, peak normalisation to
-[-1, 1], Git-LFS pointer detection, bounded retries, ``AudioDecodeError`` after the
-last failure.  The reference decodes through librosa/soundfile, which are not part
+[-1, 1], Git-LFS pointer detection, ``AudioReadConfig`` retries for failures that can be
+transient (I/O errors, empty payloads) with ``AudioDecodeError`` after the last one; the
+RIFF parser's verdict on the bytes is deterministic and is reported at once, unretried.  The reference decodes through librosa/soundfile, which are not part
 of this package; RIFF/WAVE (PCM 8/16/24/32-bit, IEEE float 32/64) is parsed here,
 which covers the reference's datasets and its synthetic generator
 (``scripts/build_synthetic_ravdess_dataset.py``).
@@ -36,28 +37,39 @@ class AudioDecodeError(OSError):
 
 
 def prepare_audio_buffer(raw_audio) -> NDArray[np.float32]:
-    """float32 cast, mono (float32 mean over the channel axis), non-finite -> 0, peak-normalise.
-
-    Order as on the reference's primary path: ``librosa.load(sr=None)`` mixes down (``mono=True``)
-    BEFORE ``_prepare_audio_buffer`` applies ``nan_to_num`` (audio_utils.py:104-110), so a NaN or inf
-    in one channel zeroes that frame instead of being dropped from the mean.  (The soundfile fallback
-    scrubs first; it only runs when librosa fails.)  The device kernel ``k_prepare_convert`` does the same."""
+    """The reference's ``_prepare_audio_buffer`` (audio_utils.py:53-60), same contract and same order:
+    float32 cast, non-finite -> 0, THEN mono (float32 mean over the channel axis of ``[frames, channels]``),
+    peak-normalise.  A NaN or inf in one channel of a 2-D input is therefore dropped from that frame's mean
+    (the soundfile-fallback behaviour, audio_utils.py:135-138).  File reads do not hand 2-D data to this
+    function: like the reference's primary path they mix down first (:func:`mix_down_like_librosa_load`)."""
     buf = np.array(raw_audio, dtype=np.float32, copy=True)
+    np.nan_to_num(buf, copy=False, nan=0.0, posinf=0.0, neginf=0.0)
     if buf.ndim == 2:
         if buf.shape[1] == 0:
             buf = np.empty(0, dtype=np.float32)
         else:
-            with np.errstate(invalid="ignore", over="ignore"):
-                buf = np.asarray(np.mean(buf, axis=1, dtype=np.float32), dtype=np.float32)
+            buf = np.asarray(np.mean(buf, axis=1, dtype=np.float32), dtype=np.float32)
     elif buf.ndim != 1:
         raise OSError(f"Unsupported audio shape: {buf.shape}")
-    np.nan_to_num(buf, copy=False, nan=0.0, posinf=0.0, neginf=0.0)
     if buf.size == 0:
         raise OSError("Audio file contains no samples.")
     peak = float(np.max(np.abs(buf)))
     if peak == 0:
         return np.zeros_like(buf)
     return buf / peak
+
+
+def mix_down_like_librosa_load(frames) -> NDArray[np.float32]:
+    """The mono mix-down ``librosa.load(path, sr=None)`` performs before ``read_audio_file`` sees the samples
+    (audio_utils.py:104-110; ``mono=True`` is librosa's default): the float32 mean over channels of the decoded
+    ``[frames, channels]`` block, with NO scrub in front -- a NaN or inf in one channel makes the whole frame
+    non-finite, and ``_prepare_audio_buffer`` then zeroes it.  This is the order ``read_audio_file`` and the
+    device kernel ``k_prepare_convert`` follow (both stand in for ``librosa.load`` + ``_prepare_audio_buffer``)."""
+    buf = np.asarray(frames, dtype=np.float32)
+    if buf.ndim == 2 and buf.shape[1] > 0:
+        with np.errstate(invalid="ignore", over="ignore"):
+            buf = np.asarray(np.mean(buf, axis=1, dtype=np.float32), dtype=np.float32)
+    return buf
 
 
 def _parse_wave(data: bytes):
@@ -211,7 +223,7 @@ def read_audio_file(
                 start_seconds=float(start_seconds or 0.0),
                 duration_seconds=float(duration_seconds) if duration_seconds is not None else None,
             )
-            return prepare_audio_buffer(samples), int(rate)
+            return prepare_audio_buffer(mix_down_like_librosa_load(samples)), int(rate)
         except AudioDecodeError as err:
             # the parser's verdict on these bytes is deterministic: retrying (and sleeping) cannot change
             # it.  Only WAVE is decoded here (module docstring); name the container / encoding at once.

@@ -24,35 +24,15 @@
 
 namespace serhip {
 
-// Build switches of this header.  All default to the shipped form; none is set by __graft_entry__.build().
-//   SERHIP_K1_WAVES, SERHIP_K1_OPAQUE_LANE, SERHIP_K1_OPAQUE_LOAD, SERHIP_K1_WAIT_FENCED   tuning parameters (below)
-//   SERHIP_K1_STAMPS=1                    diagnostic build: per-phase cycle sums
-//   SERHIP_EXP_K1_*=1                     the A/B and timing-only variants behind DESIGN.md's table of k_stft_frames
-//                                         variants (scripts/experiments/ab_bench.sh builds them next to the shipped
-//                                         library): PLAIN_STORES, PEAKS_ALL_LANES, CMAX_PER_FRAME and
-//                                         LOADS_AFTER_UNPACK restore the form a row replaced (results identical);
-//                                         HOT_STORES, HOT_LOADS and ST34 are timing-only (results are garbage).
-#ifndef SERHIP_K1_WAVES
-#define SERHIP_K1_WAVES 16
-#endif
-// Opaque copies of the lane id stop the compiler from hoisting lane-derived addresses out of the frame
-// loop.  In the frame loader (whose zero-padding path holds 32 of them) that keeps the kernel spill-free;
-// in the second half of a frame the hoisted addresses fit and save ~40 VALU instructions per frame.
-#ifndef SERHIP_K1_OPAQUE_LANE
-#define SERHIP_K1_OPAQUE_LANE 0
-#endif
-#ifndef SERHIP_K1_OPAQUE_LOAD
-#define SERHIP_K1_OPAQUE_LOAD 1
-#endif
-// k_stft_frames runs ONE workgroup per CU: its waves share the 21 KB of twiddle/window tables in LDS and
-// each owns an 8.5 KB transpose buffer.  16 waves = 4 per SIMD at <= 128 VGPRs fill the 160 KB of LDS;
-// measured on MI355X (12.5k clips): 8 waves 4.2 ms, 12 waves 2.9 ms, 16 waves 2.8 ms.
-// Diagnostic build only (-DSERHIP_K1_STAMPS=1): per-phase shader-cycle sums of every wave, taken with s_memtime
-// at the points where the wave already waits for lgkmcnt(0) (s_memtime shares that counter with LDS), written
-// to Scratch::mel (unused by this kernel) at the end.  Never in a timed or shipped build.
-#ifndef SERHIP_K1_WAIT_FENCED
-#define SERHIP_K1_WAIT_FENCED 1
-#endif
+// This header holds the shipped form only.  The A/B and timing-only variants behind DESIGN.md's tables of
+// k_stft_frames experiments (cache policies of the stores, one atomic per frame, hot loads / hot stores, three
+// quarters of the magnitude bytes, ...) live in scripts/experiments/variants/ as a patch against this file
+// (scripts/experiments/README.md) -- several of them produce garbage on purpose and must not be one -D away
+// from a product build.  One switch remains:
+//   SERHIP_K1_STAMPS=1   diagnostic build: per-phase shader-cycle sums of every wave of k_stft_frames, taken with
+//                        s_memtime at the points where the wave already waits for lgkmcnt(0) (s_memtime shares that
+//                        counter with LDS), written to Scratch::mel (unused by this kernel) and printed by the host
+//                        (DESIGN.md section 4, round 2).  Results stay correct; never in a timed or shipped build.
 #ifndef SERHIP_K1_STAMPS
 #define SERHIP_K1_STAMPS 0
 #endif
@@ -66,7 +46,10 @@ namespace serhip {
 #else
 #define K1_STAMP(i)
 #endif
-constexpr int kWaves = SERHIP_K1_WAVES; // waves per workgroup in k_stft_frames
+// k_stft_frames runs ONE workgroup per CU: its waves share the 21 KB of twiddle/window tables in LDS and
+// each owns an 8.5 KB transpose buffer.  16 waves = 4 per SIMD at <= 128 VGPRs fill the 160 KB of LDS;
+// measured on MI355X (12.5k clips): 8 waves 4.2 ms, 12 waves 2.9 ms, 16 waves 2.8 ms.
+constexpr int kWaves = 16;             // waves per workgroup in k_stft_frames
 constexpr int kUnitFramesMax = 128;    // STFT frames per work unit of k_stft_frames (small calls use less)
 constexpr int kBufC = 1088;            // complex slots of one wave's LDS buffer (16 rows x stride 68)
 constexpr int kGroups = 65;            // 16-bin groups covering bins 0..1039 (1025 used)
@@ -274,13 +257,9 @@ __device__ __forceinline__ void store_lane0(float4* dst_uniform, v4f value) {
 // scripts/check_inflight_regs.py proves on the ISA that no instruction touches those registers before it.
 template <int kYounger>
 __device__ __forceinline__ void wait_samples() {
-#if SERHIP_K1_WAIT_FENCED
     __builtin_amdgcn_sched_barrier(0);
-#endif
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
-#if SERHIP_K1_WAIT_FENCED
     __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -398,11 +377,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         const int fs = t * kHop - kNfft / 2;   // < 2^31: the host rejects longer segments
         const float* seg_audio = audio + sd.offset;
         if ((fs >= 0) & (fs + kNfft <= sd.len)) {
-#if SERHIP_EXP_K1_HOT_LOADS   // timing experiment: every interior frame reads the same 8 KB of its segment
-            const float* b0 = seg_audio + (fs & 0);
-#else
             const float* b0 = seg_audio + fs;
-#endif
             const float* b1 = b0 + 1024;       // immediate offsets reach 4 KiB
             const unsigned voff = 8u * static_cast<unsigned>(lane);
             load_pair_async<0>(dst[0], b0, voff);
@@ -532,19 +507,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
     int run_seg = -1;        // segment of the frames whose largest magnitude run_max holds (see finish_frame)
     unsigned run_max = 0;
     auto finish_frame = [&, lane_outer = lane](size_t row, int seg, auto&& request_next) {
-#if SERHIP_K1_OPAQUE_LANE
-        // an opaque copy of the lane id: the addresses derived from it are recomputed per frame instead of
-        // being hoisted out of the frame loop into ~40 VGPRs that the transform needs
-        int lane = lane_outer;
-        asm volatile("" : "+v"(lane));
-#else
         const int lane = lane_outer;
-#endif
         // the transform's registers are free from here on: the next frame's samples are requested now, ahead of the
-        // unpack (1.2 % faster than behind it; SERHIP_EXP_K1_LOADS_AFTER_UNPACK: the earlier placement)
-#if !SERHIP_EXP_K1_LOADS_AFTER_UNPACK
+        // unpack (1.2 % faster than behind it)
         request_next();
-#endif
         // ---- real-FFT unpack: bins k = lane + 64r and 1024 - k from Z[k], Z[1024-k]
         float mlo[8], mhi[8];
 #pragma unroll
@@ -573,9 +539,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         }
         wave_lds_sync();  // every lane has read Z before the buffer is reused
         K1_STAMP(4)
-#if SERHIP_EXP_K1_LOADS_AFTER_UNPACK
-        request_next();
-#endif
 
         // column maximum on the bit patterns: magnitudes are non-negative, so unsigned integer order is
         // float order and v_max3_u32 needs none of the NaN canonicalisation fmaxf drags in
@@ -635,9 +598,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             }
         }
         if (want_proj) {
-#if SERHIP_EXP_K1_CMAX_PER_FRAME     // the first form: one atomic per frame, 5 % of the kernel
-            if (lane == 0) atomicMax(&sc.seg_cmax[seg], cmax_bits);
-#else
             // the segment's largest magnitude.  With chroma on it travels in the frame's peak-count word (store
             // block below) and k_segment_finish<1> reduces it.  Without chroma that kernel does not run: the
             // maximum is kept per wave over the consecutive frames it draws from one segment and sent as one
@@ -652,18 +612,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
                     run_max = __builtin_amdgcn_readfirstlane(max(run_max, cmax_bits));
                 }
             }
-#endif
         }
         // ---- store block: the LAST vector-memory operations of a frame, and always the same number of them
         // (kStoreBlock, by the kernel's template flags), so that the next frame can wait for its samples with an
         // exact count (see "sample loads").  No branch around any of them, so the count holds on every path
         // (scripts/check_inflight_regs.py): one-lane stores narrow EXEC inside their asm statement (store_lane0).
         if (want_chroma) {
-#if SERHIP_EXP_K1_PEAKS_ALL_LANES
-            // lanes without a peak fill unused slots of the row (slot peak_cap - 1 is never a peak: the host
-            // sizes rows two past the largest possible count)
-            prow[min(lane, sc.peak_cap - 1)] = lane < base ? first_peak : v2f{0.0f, 0.0f};
-#else
             // only the lanes that hold a peak store (lane 0 always does, a zero pair into slot 0 of a frame without
             // peaks: nobody reads it, the count says 0): EXEC is set from the count inside the asm statement
             {
@@ -673,13 +627,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
                 asm volatile("" : "+v"(slot));   // opaque: the byte offset is recomputed here, not kept in a register across the frame loop
                 store_pairs_masked(prow, slot * 8u, lane < base ? first_peak : v2f{0.0f, 0.0f}, mask);
             }
-#endif
-#if SERHIP_EXP_K1_CMAX_PER_FRAME
-            store_lane0(sc.peak_cnt + row, base);
-#else
             store_lane0(sc.peak_cnt + row, __builtin_amdgcn_readfirstlane(static_cast<int>(
                             ((cmax_bits + kPeakCountMask) & ~kPeakCountMask) | static_cast<unsigned>(base))));
-#endif
         }
         if (want_proj) {
             // magnitudes for k_project_frames: a linear copy of sM, float4 chunk (lane + 64u) per lane
@@ -687,17 +636,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             // stored with three zero pads so the last 16-bin group reads defined values
             const float4* mp = reinterpret_cast<const float4*>(sM);
             float4* m4 = reinterpret_cast<float4*>(sc.mags);
-#if SERHIP_EXP_K1_HOT_STORES   // timing experiment: every frame's magnitudes land in the first 1024 rows (L2-resident)
-            const size_t mrow = row & 1023;
-#else
             const size_t mrow = row;
-#endif
 #pragma unroll
-#if SERHIP_EXP_K1_ST34        // timing experiment: three quarters of the magnitude bytes
-            for (int u = 0; u < 3; ++u) m4[mags_tile_index(mrow, lane + 64 * u)] = mp[lane + 64 * u];
-#elif SERHIP_EXP_K1_PLAIN_STORES   // experiment: the default cache policy
-            for (int u = 0; u < 4; ++u) m4[mags_tile_index(mrow, lane + 64 * u)] = mp[lane + 64 * u];
-#else
             // streaming (nt) stores: the rows are read once, by another kernel, long after they have left the L2;
             // store acknowledgements come back sooner and with them the in-order vmcnt of the next sample loads
             // (measured: kernel -3.7 %)
@@ -705,18 +645,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
                 const float4 val = mp[lane + 64 * u];
                 __builtin_nontemporal_store(v4f{val.x, val.y, val.z, val.w}, reinterpret_cast<v4f*>(m4 + mags_tile_index(mrow, lane + 64 * u)));
             }
-#endif
             store_lane0(m4 + mags_tile_index(mrow, 256), v4f{mhi[0], 0.0f, 0.0f, 0.0f});   // lane 0 holds bin 1024
         }
         wave_lds_sync();  // sM reads done before the next frame overwrites the buffer
         K1_STAMP(7)
     };
     // vector-memory operations in the store block of finish_frame
-#if SERHIP_EXP_K1_ST34
-    constexpr int kStoreBlock = (kChroma ? 2 : 0) + (kProj ? 4 : 0);
-#else
     constexpr int kStoreBlock = (kChroma ? 2 : 0) + (kProj ? 5 : 0);
-#endif
     v2f v[16];
     bool more = seek();
     if (more) {

@@ -21,13 +21,12 @@
 namespace serhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// 16-frame MFMA tiles per wave (SERHIP_K2_HALVES): 2 = 32 frames per wave, three waves per workgroup (the default);
-// 1 = six waves of one tile (fewer registers, more waves per SIMD: measured 18 % slower); 3 = two waves of three tiles.
-// Either way a workgroup covers 96 frames = one 3 s clip and fetches each B row once.
-#ifndef SERHIP_K2_HALVES
-#define SERHIP_K2_HALVES 2
-#endif
-constexpr int kProjHalves = SERHIP_K2_HALVES;
+// 16-frame MFMA tiles per wave: 2 = 32 frames per wave, three waves per workgroup.  The code is written for
+// 1..3 (all parity-green; measured 1.52 / 1.29 / 1.29 ms per 12 500 clips: one tile per wave pays the per-group
+// costs -- B reads, barrier, program word -- per 16 frames, three tiles leave a third fewer waves); this is a
+// design constant, not a build switch.  Either way a workgroup covers 96 frames = one 3 s clip and fetches each
+// B row once.
+constexpr int kProjHalves = 2;
 static_assert(kProjHalves >= 1 && kProjHalves <= 3, "one to three tiles per wave");
 constexpr int kProjTile = 16 * kProjHalves;   // frames per wave
 constexpr int kProjWaves = 6 / kProjHalves;   // waves per workgroup
@@ -71,15 +70,9 @@ __device__ __forceinline__ float row_max(float v) {
     return fmaxf(v, dpp_mov<0x140>(v));   // row_mirror
 }
 
-// magnitude fragment load; SERHIP_EXP_K2_NT_LOADS marks it streaming (nt)
-__device__ __forceinline__ float4 load_mags(const float4* p) {
-#if SERHIP_EXP_K2_NT_LOADS
-    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-    return float4{v[0], v[1], v[2], v[3]};
-#else
-    return *p;
-#endif
-}
+// magnitude fragment load (default cache policy: streaming `nt` loads measured +5 %, the second half of each
+// line is then fetched again)
+__device__ __forceinline__ float4 load_mags(const float4* p) { return *p; }
 
 __device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);

@@ -5,7 +5,20 @@
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and prototypes only: the library is loaded with dlopen on first use
+// RCCL is loaded with dlopen on first use and called through pointers: only its types are needed at compile
+// time.  Where the RCCL headers are absent the few types this file names are declared here, with the values
+// of rccl.h (nccl.h 2.x ABI), so that the library still builds and reports SERHIP_E_UNSUPPORTED at run time
+// if librccl cannot be loaded.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+}
+#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -942,25 +955,39 @@ int serhip_plan_feature_dim(const serhip_plan* plan) { return plan ? plan->dim :
 namespace {
 struct RcclApi {
     void* lib = nullptr;
-    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
-    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
-    decltype(&ncclCommDestroy) comm_destroy = nullptr;
-    decltype(&ncclBroadcast) broadcast = nullptr;
-    decltype(&ncclGroupStart) group_start = nullptr;
-    decltype(&ncclGroupEnd) group_end = nullptr;
-    decltype(&ncclGetErrorString) error_string = nullptr;
+    // prototypes spelled out (not decltype(&ncclXxx)): nothing here depends on the header's declarations
+    ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*group_start)() = nullptr;
+    ncclResult_t (*group_end)() = nullptr;
+    const char* (*error_string)(ncclResult_t) = nullptr;
     std::string problem;
 };
-// a process that already holds an RCCL (torch's own copy) gets that one: dlopen by soname returns it
+// a process that already holds an RCCL (torch's own copy) gets that one: dlopen by soname returns it.
+// SERHIP_RCCL_LIBRARY names the library to load instead (a site-specific build; the host tests point it at
+// a file that does not exist to drive the failure path).
 const RcclApi* rccl_api() {
     static const RcclApi api = [] {
         RcclApi a;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        std::string tried;
+        std::vector<std::string> names;
+        if (const char* env = std::getenv("SERHIP_RCCL_LIBRARY"); env && *env)
+            names.push_back(env);
+        else
+            names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::string why;
+        for (const std::string& name : names) {
+            a.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (a.lib) break;
+            const char* e = dlerror();   // ONE call: it returns the message and clears it
+            why = e ? e : "unknown error";
+            tried += (tried.empty() ? "" : ", ") + name;
         }
         if (!a.lib) {
-            a.problem = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "unknown error");
+            a.problem = "RCCL could not be loaded (tried " + tried + "): " + why;
             return a;
         }
         auto sym = [&](const char* n) {
@@ -972,6 +999,7 @@ const RcclApi* rccl_api() {
         a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(sym("ncclCommInitRank"));
         a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(sym("ncclCommDestroy"));
         a.broadcast = reinterpret_cast<decltype(a.broadcast)>(sym("ncclBroadcast"));
+        a.all_gather = reinterpret_cast<decltype(a.all_gather)>(sym("ncclAllGather"));
         a.group_start = reinterpret_cast<decltype(a.group_start)>(sym("ncclGroupStart"));
         a.group_end = reinterpret_cast<decltype(a.group_end)>(sym("ncclGroupEnd"));
         a.error_string = reinterpret_cast<decltype(a.error_string)>(sym("ncclGetErrorString"));
@@ -1030,7 +1058,19 @@ int serhip_allgather_rows(serhip_comm* comm, const float* shard_dev, const int64
         if (rows_per_rank[r] < 0) return fail(SERHIP_E_INVALID, "serhip_allgather_rows: negative row count");
     if (rows_per_rank[comm->rank] > 0 && !shard_dev) return fail(SERHIP_E_INVALID, "serhip_allgather_rows: NULL shard");
     const RcclApi& api = *rccl_api();
+    if (!api.problem.empty()) return fail(SERHIP_E_UNSUPPORTED, "serhip_allgather_rows: " + api.problem);
     HIP_TRY(hipSetDevice(comm->device));
+    bool equal = rows_per_rank[0] > 0;
+    for (int r = 1; r < comm->world && equal; ++r) equal = rows_per_rank[r] == rows_per_rank[0];
+    if (equal) {
+        // the common case (shard_bounds pads nothing when world divides the row count; bench.py's weak scaling):
+        // ONE ncclAllGather -- over xGMI every rank sends its shard to its 7 peers directly
+        const ncclResult_t r = api.all_gather(shard_dev, out_dev, static_cast<size_t>(rows_per_rank[0]) * dim, ncclFloat32,
+                                              comm->comm, static_cast<hipStream_t>(stream));
+        if (r != ncclSuccess) return rccl_fail("serhip_allgather_rows (ncclAllGather)", r);
+        return SERHIP_OK;
+    }
+    // uneven or empty shards: one grouped call of a broadcast per non-empty shard (no padding, no extra copy)
     ncclResult_t r = api.group_start();
     if (r != ncclSuccess) return rccl_fail("serhip_allgather_rows", r);
     int64_t row = 0;
@@ -1350,11 +1390,16 @@ int serhip_tuning_from_peaks(serhip_plan* plan, const float* pitch_mag, const in
     int cap = 1;
     size_t total = 0;
     for (int t = 0; t < n_frames; ++t) {
-        if (frame_counts[t] < 0 || frame_counts[t] > (1 << 16))
-            return fail(SERHIP_E_INVALID, "serhip_tuning_from_peaks: frame " + std::to_string(t) + " has a bad peak count");
+        // the count shares its scratch word with the frame-max key: the kernel reads the low 10 bits only
+        if (frame_counts[t] < 0 || frame_counts[t] > static_cast<int>(kPeakCountMask))
+            return fail(SERHIP_E_INVALID, "serhip_tuning_from_peaks: frame " + std::to_string(t) + " has a peak count outside 0.." +
+                                              std::to_string(kPeakCountMask));
         cap = std::max(cap, frame_counts[t]);
         total += static_cast<size_t>(frame_counts[t]);
     }
+    // the host builds [n_frames][cap] rows: bound them (16 Mi entries = 128 MiB) instead of trusting the caller
+    if (static_cast<size_t>(n_frames) * static_cast<size_t>(cap) > (static_cast<size_t>(1) << 24))
+        return fail(SERHIP_E_UNSUPPORTED, "serhip_tuning_from_peaks: n_frames x largest count exceeds 2^24 peak slots");
     if (total > 0 && !pitch_mag) return fail(SERHIP_E_INVALID, "serhip_tuning_from_peaks: pitch_mag is NULL");
     // the scratch rows k_stft_frames would have written: [frame][cap] (pitch, mag) + the counts
     const size_t frames = (static_cast<size_t>(n_frames) + 15) / 16 * 16;

@@ -103,13 +103,27 @@ def _replacing(destination: Path):
         raise
 
 
-def write_prepared_feature_payload(path, *, x_train, x_dev, x_test, y_train: Sequence[str], y_dev: Sequence[str],
-                                   y_test: Sequence[str], metadata: Mapping[str, object]) -> Path:
-    """Publish one payload file (same keyword surface as the reference's writer); returns its path."""
+def default_prepared_payload_path(settings) -> Path:
+    """Where the reference publishes the fast profile's payload: ``settings.tmp_folder /
+    "prepared-training-fast.npz"`` (training_readiness.py:880-882 with the profile name this package
+    implements)."""
+    folder = getattr(settings, "tmp_folder", None)
+    if folder is None:
+        raise ValueError("write_prepared_feature_payload needs `path` or settings with a `tmp_folder`.")
+    return Path(folder) / DEFAULT_FILE_NAME
+
+
+def write_prepared_feature_payload(path=None, *, settings=None, x_train, x_dev, x_test, y_train: Sequence[str],
+                                   y_dev: Sequence[str], y_test: Sequence[str],
+                                   metadata: Mapping[str, object]) -> Path:
+    """Publish one payload file; returns its path.  Keyword surface of the reference's writer
+    (training_orchestration.py:842-853: ``settings``, the six arrays, ``metadata``, ``path=None``): without
+    ``path`` the file goes to the reference's default location under ``settings.tmp_folder``.  ``path`` is
+    also accepted as the first positional argument."""
     given = {"x_train": x_train, "x_dev": x_dev, "x_test": x_test, "y_train": y_train, "y_dev": y_dev,
              "y_test": y_test, "metadata_json": metadata}
     arrays = {name: _encode(kind, given[name]) for name, kind in SCHEMA}
-    destination = Path(path)
+    destination = Path(path) if path is not None else default_prepared_payload_path(settings)
     with _replacing(destination) as handle:
         np.savez_compressed(handle, **arrays)
     return destination

@@ -93,7 +93,8 @@ def require_accelerated(flags: FeatureFlags) -> None:
 
 @dataclass(frozen=True)
 class AudioReadConfig:
-    """Retry behaviour for audio loading."""
+    """How often and how patiently ``read_audio_file`` retries a read that failed for a possibly transient reason
+    (fields and defaults of config/schema.py:243-248)."""
 
     max_retries: int = 3
     retry_delay_seconds: float = 1.0
@@ -101,7 +102,8 @@ class AudioReadConfig:
 
 @dataclass(frozen=True)
 class PoolingWindow:
-    """Temporal window used when pooling encoded frame features."""
+    """One ``[start_seconds, end_seconds)`` span over which frame embeddings are pooled (repr/backend.py:19-35:
+    finite, start >= 0, end > start)."""
 
     start_seconds: float
     end_seconds: float
@@ -118,7 +120,8 @@ class PoolingWindow:
 
 @dataclass(frozen=True)
 class EncodedSequence:
-    """Frame-level encoded representation with explicit temporal boundaries."""
+    """What ``encode_sequence`` returns: a ``[frames, D]`` embedding matrix plus the start and end time of every
+    frame and the id of the backend that produced it (validation rules of repr/backend.py:37-78)."""
 
     embeddings: EmbeddingMatrix
     frame_start_seconds: TimeVector
@@ -151,7 +154,7 @@ class EncodedSequence:
 
 @dataclass(frozen=True)
 class FeatureFrame:
-    """A frame-level feature vector with explicit temporal boundaries."""
+    """One analysis window of a file with its float64 feature vector (features/feature_extractor.py:26-32)."""
 
     start_seconds: float
     end_seconds: float
@@ -192,7 +195,8 @@ def overlap_frame_mask(encoded: EncodedSequence, window: PoolingWindow) -> NDArr
 
 @runtime_checkable
 class FeatureBackend(Protocol):
-    """Backend protocol for sequence encoding and temporal pooling."""
+    """Structural type every representation backend satisfies: ``backend_id``, ``feature_dim``,
+    ``encode_sequence`` and ``pool`` (repr/backend.py:114-143; runtime-checkable like the reference's)."""
 
     @property
     def backend_id(self) -> str: ...
@@ -207,6 +211,6 @@ class FeatureBackend(Protocol):
 
 @runtime_checkable
 class VectorFeatureBackend(FeatureBackend, Protocol):
-    """Optional convenience protocol for direct vector extraction."""
+    """Backends that can also turn a whole clip into ONE vector (``extract_vector``, repr/backend.py:146-155)."""
 
     def extract_vector(self, audio: NDArray[np.float32], sample_rate: int) -> FeatureVector: ...

@@ -54,12 +54,15 @@ def test_read_raw_clip_headers_and_segments(tmp_path):
         read_raw_clip(str(p), start_seconds=-1.0)
 
 
-def test_host_prepare_follows_the_librosa_load_order():
-    """Host ``prepare_audio_buffer`` == the oracle's restatement of librosa.load's mix-down followed by
-    ``_prepare_audio_buffer``: 1..9 channels (numpy's pairwise order from 8 on), non-finite samples in one
-    channel, the reference's own known answer (tests/suites/unit/utils/test_audio_utils.py:14-27)."""
+def test_host_prepare_orders_match_the_reference_functions():
+    """Two orders exist in the reference and both are kept: ``prepare_audio_buffer`` IS ``_prepare_audio_buffer``
+    (scrub, then mono: audio_utils.py:55-57), while a file read mixes down first like ``librosa.load(mono=True)``
+    and scrubs afterwards (audio_utils.py:104-110).  1..9 channels (numpy's pairwise order from 8 on), non-finite
+    samples in one channel, the reference's own known answer (tests/suites/unit/utils/test_audio_utils.py:14-27).
+    No reference fixture holds a multichannel float file with NaN: the difference between the orders is
+    parity unpinned; the known answers below are hand-derived from the two code paths."""
     from oracle import ser_fast_path as ofp
-    from ser_amd.audio_io import prepare_audio_buffer
+    from ser_amd.audio_io import mix_down_like_librosa_load, prepare_audio_buffer
 
     rng = np.random.default_rng(3)
     for ch in range(1, 10):
@@ -68,11 +71,35 @@ def test_host_prepare_follows_the_librosa_load_order():
             x[5, 1] = np.nan
             x[9, 0] = np.inf
         arg = x if ch > 1 else x[:, 0]
-        np.testing.assert_array_equal(prepare_audio_buffer(arg), ofp.read_audio_prepared(arg))
+        np.testing.assert_array_equal(prepare_audio_buffer(arg), ofp.prepare_audio_buffer(arg))
+        np.testing.assert_array_equal(prepare_audio_buffer(mix_down_like_librosa_load(arg)), ofp.read_audio_prepared(arg))
     two = np.array([[0.5, np.nan], [0.25, 0.75], [np.inf, -np.inf]], dtype=np.float32)
-    np.testing.assert_array_equal(prepare_audio_buffer(two), np.array([0.0, 1.0, 0.0], dtype=np.float32))
+    # file order: frames 0 and 2 are non-finite after the mean -> 0; frame 1 = 0.5 -> peak
+    np.testing.assert_array_equal(prepare_audio_buffer(mix_down_like_librosa_load(two)),
+                                  np.array([0.0, 1.0, 0.0], dtype=np.float32))
+    # the reference function's order: scrub first -> [[0.5, 0], [0.25, 0.75], [0, 0]] -> means [0.25, 0.5, 0] -> / 0.5
+    np.testing.assert_array_equal(prepare_audio_buffer(two), np.array([0.5, 1.0, 0.0], dtype=np.float32))
     np.testing.assert_array_equal(prepare_audio_buffer(np.array([[0.2, 0.0], [0.4, 0.0]], np.float32)),
                                   np.array([0.5, 1.0], np.float32))
+
+
+def test_file_read_uses_the_librosa_load_order(tmp_path):
+    """A stereo float32 WAVE with a NaN in one channel, read through ``read_audio_file``: the frame is zeroed
+    (mix-down first), not averaged over the finite channel."""
+    import struct
+
+    from ser_amd.audio_io import read_audio_file
+
+    frames = np.array([[0.5, np.nan], [0.25, 0.75]], dtype="<f4")
+    body = frames.tobytes()
+    fmt = struct.pack("<HHIIHH", 3, 2, 8000, 8000 * 8, 8, 32)
+    data = b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(body)) + b"WAVE" + b"fmt " + \
+        struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(body)) + body
+    p = tmp_path / "nan.wav"
+    p.write_bytes(data)
+    audio, rate = read_audio_file(str(p))
+    assert rate == 8000
+    np.testing.assert_array_equal(audio, np.array([0.0, 1.0], dtype=np.float32))
 
 
 @pytest.mark.gpu

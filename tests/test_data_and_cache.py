@@ -110,6 +110,26 @@ def test_prepared_cache_round_trip_and_validation(tmp_path):
                                        y_dev=ys[1], y_test=ys[2], metadata={"x": object()})
 
 
+def test_prepared_cache_writer_takes_the_references_keywords(tmp_path):
+    """The reference's call shape (training_orchestration.py:842-856): keyword-only ``settings``, the six
+    arrays, ``metadata`` and ``path=None``; without a path the file goes to
+    ``settings.tmp_folder / "prepared-training-fast.npz"`` (training_readiness.py:880-882)."""
+    from types import SimpleNamespace as NS
+
+    from ser_amd.prepared_cache import default_prepared_payload_path
+
+    x = np.ones((2, 187))
+    settings = NS(tmp_folder=tmp_path / "tmp")
+    kw = dict(x_train=x, x_dev=x[:0], x_test=x, y_train=["a", "b"], y_dev=[], y_test=["a", "b"], metadata={"k": 1})
+    p = write_prepared_feature_payload(settings=settings, **kw)
+    assert p == tmp_path / "tmp" / "prepared-training-fast.npz" == default_prepared_payload_path(settings) and p.exists()
+    q = write_prepared_feature_payload(settings=settings, path=tmp_path / "elsewhere.npz", **kw)
+    assert q == tmp_path / "elsewhere.npz" and q.exists()
+    assert read_prepared_feature_payload(q, feature_shape=(4, 187)).metadata == {"k": 1}
+    with pytest.raises(ValueError, match="needs `path` or settings"):
+        write_prepared_feature_payload(**kw)
+
+
 class _Utt:
     """What the loader reads from the reference's ``Utterance`` (data/manifest types)."""
 

@@ -263,6 +263,43 @@ def test_read_audio_file(tmp_path):
         read_audio_file(str(adpcm), audio_read_config=AudioReadConfig(max_retries=3, retry_delay_seconds=5.0))
 
 
+def test_audio_read_config_retries_transient_failures(tmp_path, monkeypatch):
+    """What ``AudioReadConfig`` does here (reference loop: audio_utils.py:96-162): every failure that is not the
+    parser's deterministic verdict -- an I/O error while reading, an empty payload -- is retried up to
+    ``max_retries`` times with ``retry_delay_seconds`` between attempts; the last failure becomes
+    ``AudioDecodeError("Error reading <path>")`` chained to it, except for segment reads, which re-raise
+    the original exception like the reference (:121-131)."""
+    import ser_amd.audio_io as aio
+    from ser_amd.synth import ravdess_sine_clip, write_wav_pcm16
+
+    path = tmp_path / "clip.wav"
+    write_wav_pcm16(path, np.rint(ravdess_sine_clip(1, 2) * 32768).astype(np.int16), 16000)
+    real_decode, calls, naps = aio.decode_file, [], []
+
+    def flaky(p, **kw):
+        calls.append(p)
+        if len(calls) <= 2:
+            raise OSError(5, "Input/output error")
+        return real_decode(p, **kw)
+
+    monkeypatch.setattr(aio, "decode_file", flaky)
+    monkeypatch.setattr(aio.time, "sleep", naps.append)
+    audio, rate = aio.read_audio_file(str(path), audio_read_config=AudioReadConfig(max_retries=3, retry_delay_seconds=0.25))
+    assert rate == 16000 and audio.shape == (24000,) and len(calls) == 3 and naps == [0.25, 0.25]
+    # one attempt fewer than failures: the reference's terminal error, chained to the last failure, no sleep after it
+    calls.clear()
+    naps.clear()
+    with pytest.raises(AudioDecodeError, match=f"Error reading {path}") as info:
+        aio.read_audio_file(str(path), audio_read_config=AudioReadConfig(max_retries=2, retry_delay_seconds=0.5))
+    assert isinstance(info.value.__cause__, OSError) and len(calls) == 2 and naps == [0.5]
+    # segment reads re-raise the original exception on the last attempt
+    calls.clear()
+    naps.clear()
+    with pytest.raises(OSError, match="Input/output error"):
+        aio.read_audio_file(str(path), start_seconds=0.1, audio_read_config=AudioReadConfig(max_retries=2, retry_delay_seconds=0.5))
+    assert len(calls) == 2 and naps == [0.5]
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """Without a GPU the product path must raise; it never routes through the CPU oracle."""
     import torch

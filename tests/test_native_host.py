@@ -190,3 +190,27 @@ def test_comm_entry_points_reject_bad_arguments_without_touching_rccl(native_lib
     assert native_lib.serhip_comm_create(None, None, 0, 1, ctypes.byref(handle)) == -1
     assert native_lib.serhip_allgather_rows(None, None, None, 187, None, None) == -1
     native_lib.serhip_comm_destroy(None)   # a no-op, like free(NULL)
+
+
+def test_rccl_that_cannot_be_loaded_is_reported_not_crashed():
+    """with RCCL unloadable the comm entry points must return SERHIP_E_UNSUPPORTED (-4) with a message
+    (one dlerror() call; the old code built a std::string from NULL).  The loader's result is cached per process,
+    so this runs in a child whose SERHIP_RCCL_LIBRARY names a file that does not exist.  No GPU is touched:
+    serhip_comm_unique_id consults the loader before anything else."""
+    import os
+    import sys
+
+    code = (
+        "import ctypes, sys\n"
+        f"lib = ctypes.CDLL({str(ROOT / 'ser_amd' / 'libserhip.so')!r})\n"
+        "lib.serhip_last_error.restype = ctypes.c_char_p\n"
+        "buf = (ctypes.c_ubyte * 128)()\n"
+        "rc = lib.serhip_comm_unique_id(buf)\n"
+        "print(rc, lib.serhip_last_error().decode())\n"
+    )
+    env = dict(os.environ, SERHIP_RCCL_LIBRARY="/nonexistent/librccl-not-here.so.1")
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr
+    rc, message = done.stdout.strip().split(" ", 1)
+    assert int(rc) == -4
+    assert "RCCL could not be loaded" in message and "librccl-not-here" in message
