@@ -235,6 +235,54 @@ int serhip_profile_read(serhip_ctx* ctx, int kind, double* total_ms, int64_t* la
 int serhip_tuning_from_peaks(serhip_plan* plan, const float* pitch_mag, const int32_t* frame_counts,
                              int32_t n_frames, float* tuning_out);
 
+/* ---- ingest: files and host buffers on their way to the GPU (host-only code: no GPU touched) ----
+ *
+ * serhip_read_wav_batch reads `n_files` RIFF/WAVE files with a team of threads straight into caller-owned host
+ * memory `dst` (meant to be pinned, so that the slab goes to the GPU in one asynchronous copy) and parses the
+ * headers in place; serhip_prepare_audio then converts / mixes down / normalises the payloads on the device.
+ * Together they replace, for PCM16 and float32 WAVE files, the per-file librosa.load(path, sr=None, offset,
+ * duration) of ser/_internal/utils/audio_utils.py:99-113 and the multiprocessing.Pool over files around it
+ * (ser/_internal/data/data_loader.py:368-379: worker processes decoding while others extract).
+ *   paths_blob / path_offset  the paths, NUL-terminated, back to back; path i starts at paths_blob + path_offset[i]
+ *   start_seconds / duration_seconds  [n_files] or NULL; NaN = not given (whole file).  Frame range as in the
+ *                 reference's segment reads: first = (int64)(start * rate), count = (int64)(duration * rate)
+ *   dst_offset / dst_capacity  [n_files] the region of `dst` each WHOLE file is read into (header included);
+ *                 regions must not overlap and should start 16-byte aligned; capacity >= the file's size
+ *   clips         [n_files] out: per file a status and, for SERHIP_WAV_OK, where its selected frames sit in `dst`
+ *                 (raw_offset is a multiple of the sample size: what serhip_prepare_audio's clip_raw_offset takes)
+ * Every status other than SERHIP_WAV_OK means "not handled here": the caller's own reader (ser_amd/audio_io.py)
+ * then decodes the file on the host or raises the reference's error for it (FileNotFoundError, AudioIntegrityError
+ * for Git-LFS pointers, AudioDecodeError, "contains no samples").  Returns 0, or SERHIP_E_INVALID for bad arguments. */
+#define SERHIP_WAV_OK 0
+#define SERHIP_WAV_HOST_DECODE 1   /* a WAVE file in an encoding the device path does not take (8/24/32-bit PCM, float64, ...) */
+#define SERHIP_WAV_IO 2            /* open / fstat / read failed, or not a regular file */
+#define SERHIP_WAV_LFS_POINTER 3   /* a Git-LFS pointer in place of audio bytes */
+#define SERHIP_WAV_NOT_WAVE 4      /* not RIFF/WAVE, or no usable fmt / data chunk */
+#define SERHIP_WAV_NOSPACE 5       /* the file is larger than its region */
+#define SERHIP_WAV_EMPTY 6         /* the selection holds no frames */
+typedef struct serhip_wav_clip {
+    int64_t raw_offset;     /* byte offset in dst of the first selected frame */
+    int64_t frames;         /* selected sample frames */
+    int32_t sample_rate;
+    int32_t channels;
+    int32_t sample_format;  /* SERHIP_SAMPLE_S16 or SERHIP_SAMPLE_F32 */
+    int32_t status;         /* SERHIP_WAV_* */
+} serhip_wav_clip;
+int serhip_read_wav_batch(const char* paths_blob, const int64_t* path_offset, int64_t n_files,
+                          const double* start_seconds, const double* duration_seconds,
+                          const int64_t* dst_offset, const int64_t* dst_capacity, void* dst, int64_t dst_bytes,
+                          int threads, serhip_wav_clip* clips);
+
+/* Sizes of many files with a team of threads (one stat each; -1 = missing or not a regular file): what the slab
+ * planner of the loader needs before it can give every file its region.  Replaces nothing in the reference (its
+ * workers open files one by one); exists so that the per-file cost of a 100k-file corpus is not Python's. */
+int serhip_stat_files(const char* paths_blob, const int64_t* path_offset, int64_t n_files, int threads, int64_t* sizes);
+
+/* memcpy of one large host buffer by a team of threads: pageable caller memory (a numpy array) -> pinned staging
+ * at more than one core's copy bandwidth, so that staging keeps up with the H2D DMA behind it (the reference has
+ * no counterpart: its arrays never leave the host). */
+int serhip_parallel_memcpy(void* dst, const void* src, int64_t bytes, int threads);
+
 /* ---- host-only helpers (no GPU touched; used by the CPU test-suite) ---- */
 
 /* Copy one host-built constant table of the fast plan into `out` (f32).

@@ -4,10 +4,22 @@
 timed region; each figure is audio-seconds of input per second of wall time, with the
 fraction of the HBM roofline on SURVEY.md 8d's algorithmic bytes.  Writes one JSON document.
 
+Round 3 adds the END-TO-END ingest lines, where inputs start on the host and the figure is what a real caller
+gets: ``config2_from_files`` (>= 10 k PCM16 WAV files on tmpfs -> feature matrix on the host -> prepared-feature
+cache) and ``config3_from_host`` (12 500 float32 clips in pageable numpy memory -> features), each with the
+bounds measured in the same run (reader threads alone, pageable->pinned staging alone, pinned H2D alone, kernels
+alone) and the pipelined figure as a fraction of the tightest one.
+
     python scripts/bench_configs.py > gpurun_out/configs.json
+    python scripts/bench_configs.py --only config2_from_files,config3_from_host
+    python scripts/bench_configs.py --only generic_short      # 70 000 x 700-sample segments (k_dft_frames path)
 """
+import argparse
 import json
+import os
+import shutil
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -37,10 +49,20 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps, out
 
 
-def main():
-    eng = get_engine()
-    res = {}
-    # ---- config 1: one 4.37 s recording, 3 s / 1 s windows (latency case: 5 segments)
+def h2d_rate(eng, nbytes=256 << 20, reps=5):
+    """GB/s of an asynchronous copy from pinned host memory to the GPU (the PCIe bound of both ingest paths)."""
+    pin = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    dev = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)
+    dev.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dev.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    return nbytes * reps / (time.perf_counter() - t0) / 1e9
+
+
+def config1(eng, res):
     audio = eng.to_device(sample_wav_like())
     starts, ends = sliding_window_bounds(int(audio.numel()), SR, 3, 1)
     offs, lens = starts, ends - starts
@@ -48,7 +70,9 @@ def main():
     dt, out = timed(lambda: eng.features(audio, offs, lens, SR, FLAGS), 50)
     res["config1"] = {"what": "69 937-sample recording, 5 windows (3 s / 1 s), features on device", "ms": dt * 1e3,
                       "audio_seconds_per_s": (audio.numel() / SR) / dt}
-    # ---- config 2 scaled: 24 actors x 8 emotions x 60 repetitions of the 1.5 s synthetic RAVDESS clips
+
+
+def config2_scaled(eng, res):
     base = np.stack([ravdess_sine_clip(a, e) for a in range(1, 25) for e in range(1, 9)])
     base = base / np.abs(base).max(axis=1, keepdims=True)
     clips = eng.to_device(np.tile(base, (60, 1)).reshape(-1))
@@ -59,8 +83,9 @@ def main():
     sec = n * 1.5
     res["config2_scaled"] = {"what": f"{n} clips x 1.5 s (47 frames each)", "ms": dt * 1e3, "audio_seconds_per_s": sec / dt,
                              "hbm_roofline_frac": (sec / dt) * (4 * 24000 + 4 * 187) / 1.5 / HBM}
-    del clips
-    # ---- config 4: one hour, 3 s windows / 1 s stride through descriptors, then mean_std_pool 10 s / 5 s
+
+
+def config4(eng, res):
     hour = harmonic_clips_torch(4321, 3600, SR, eng.device).reshape(-1)
     hour = hour / hour.abs().max()
     starts, ends = sliding_window_bounds(int(hour.numel()), SR, 3, 1)
@@ -73,23 +98,202 @@ def main():
     backend = HandcraftedBackend(feature_flags=FLAGS)
     host_hour = hour.cpu().numpy()
     times = []
-    for _ in range(3):   # the first pass pays one-time costs (pooling workspace, page faults of the host buffer)
+    for _ in range(3):   # the first pass pays one-time costs (pooling workspace, staging buffers, page faults of the host buffer)
         t0 = time.perf_counter()
         enc = backend.encode_sequence(host_hour, SR)
         wins = temporal_pooling_windows(enc, window_size_seconds=10.0, window_stride_seconds=5.0)
         pooled = mean_std_pool(enc, wins)
         times.append((time.perf_counter() - t0) * 1e3)
-    res["config4_host_api"] = {"what": "same through HandcraftedBackend.encode_sequence (230 MB H2D) + "
+    res["config4_host_api"] = {"what": "same through HandcraftedBackend.encode_sequence (230 MB H2D, staged in chunks) + "
                                        "temporal_pooling_windows + mean_std_pool", "ms": min(times[1:]),
                                "first_call_ms": times[0], "pooled_shape": list(pooled.shape)}
-    del hour
-    # ---- config 5: whisper log-mel, 64 clips x 30 s
+
+
+def config5(eng, res):
     b = 64
     clips5 = harmonic_clips_torch(99, b, 30 * SR, eng.device)
     dt, out = timed(lambda: eng.whisper_logmel(clips5, n_mels=80), 10)
     sec = b * 30.0
     res["config5"] = {"what": f"{b} x 30 s clips -> [{b}, 80, 3000] log-mel", "ms": dt * 1e3,
                       "audio_seconds_per_s": sec / dt, "hbm_roofline_frac": (sec / dt) * 96000 / HBM}
+
+
+def generic_short(eng, res):
+    """The generic path (segments < 2048 samples: k_dft_frames + k_segment_finish<0>): the 70 000 x 700-sample
+    batch of tests/test_gpu_parity.py::test_more_segments_than_one_launch_holds, so that its cost per
+    audio-second is known (a batch of sub-0.128 s clips runs entirely here)."""
+    n, length = 70000, 700
+    audio = harmonic_clips_torch(7, 700, 70000, eng.device).reshape(-1)
+    offs = np.arange(n, dtype=np.int64) * length
+    lens = np.full(n, length, dtype=np.int64)
+    dt, out = timed(lambda: eng.features(audio, offs, lens, SR, FLAGS), 3)
+    sec = n * length / SR
+    res["generic_short"] = {"what": f"{n} segments x {length} samples (n_fft = {length}: direct f64 DFT path)", "ms": dt * 1e3,
+                            "audio_seconds_per_s": sec / dt,
+                            "hbm_roofline_frac": (sec / dt) * (4 * length + 4 * 187) / (length / SR) / HBM}
+
+
+def config2_from_files(eng, res):
+    """>= 10 k WAVs on tmpfs -> features (pipelined ingest) -> prepared-feature cache; bounds measured beside it."""
+    from ser_amd import AudioReadConfig, ingest
+    from ser_amd.data_loader import featurize_audio_jobs_device
+    from ser_amd.prepared_cache import write_prepared_feature_payload
+    from ser_amd.synth import write_wav_pcm16
+
+    root = Path(tempfile.mkdtemp(prefix="serhip_cfg2_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None))
+    try:
+        reps = 60
+        t0 = time.perf_counter()
+        files, labels = [], []
+        for actor in range(1, 25):
+            d = root / f"Actor_{actor:02d}"
+            d.mkdir()
+            for emo in range(1, 9):
+                pcm = np.rint(ravdess_sine_clip(actor, emo) * 32768).astype(np.int16)
+                for rep in range(reps):
+                    p = d / f"03-01-{emo:02d}-01-01-{rep:02d}-{actor:02d}.wav"
+                    write_wav_pcm16(p, pcm, SR)
+                    files.append(str(p))
+                    labels.append(f"e{emo}")
+        n = len(files)
+        sec = n * 1.5
+        gen_s = time.perf_counter() - t0
+        jobs = [(f, None, None) for f in files]
+        cfg = AudioReadConfig()
+        threads = ingest.host_threads()
+        out = {"what": f"{n} PCM16 WAV files x 1.5 s on tmpfs ({root.parent}) -> [n, 187] float64 on the host -> "
+                       "prepared-training-fast.npz", "files": n, "audio_seconds": sec, "dataset_write_s": gen_s,
+               "host_threads": threads}
+        # ---- bound 1: the reader alone (stat + native read into pinned slabs, the pipeline's own slab plan; no GPU)
+        sizes = ingest.stat_files(files, threads)
+        total = int(sizes.sum())
+        slab = max(min(ingest.DEFAULT_SLAB_BYTES, max(8 << 20, -(-total // 32))), 1 << 20)
+        slabs = ingest.plan_slabs(sizes, slab)
+        room = (sizes + 15) // 16 * 16
+        pin = torch.empty(max(int(room[lo:hi].sum()) for lo, hi in slabs), dtype=torch.uint8, pin_memory=True)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            blob, path_at = ingest.encode_paths(files)
+            ingest.stat_files(None, threads, table=(blob, path_at))
+            for lo, hi in slabs:
+                offs = np.concatenate(([0], np.cumsum(room[lo:hi])[:-1]))
+                clips = ingest.read_wav_batch(None, pin.data_ptr(), pin.numel(), offs, room[lo:hi], threads=threads,
+                                              table=(blob, path_at[lo:hi]))
+                assert not clips["status"].any()
+            best = min(best, time.perf_counter() - t0)
+        out["reader_only"] = {"s": best, "audio_seconds_per_s": sec / best, "GBps": total / best / 1e9, "slabs": len(slabs)}
+        del pin
+        # ---- bound 2: pinned H2D alone
+        gbps = h2d_rate(eng)
+        out["h2d_pinned"] = {"GBps": gbps, "audio_seconds_per_s": sec / (total / (gbps * 1e9))}
+        # ---- bound 3: kernels alone on device-resident raw bytes (prepare + features), one batch
+        raw = np.concatenate([np.fromfile(f, dtype=np.uint8, offset=44) for f in files[:192]])
+        raw_dev = torch.from_numpy(np.tile(raw, reps)).to(eng.device)
+        r_off = np.arange(n, dtype=np.int64) * 48000
+        frames = np.full(n, 24000, dtype=np.int64)
+        chans = np.ones(n, dtype=np.int32)
+
+        def kernels():
+            audio, o, fr = eng.prepare_audio(raw_dev, "s16", r_off, frames, chans)
+            return eng.features(audio, o, fr, SR, FLAGS)
+        dt, _ = timed(kernels, 5)
+        out["kernels_only"] = {"s": dt, "audio_seconds_per_s": sec / dt}
+        del raw_dev
+        # ---- end to end: sequential (round 2) and pipelined, files -> host float64 matrix
+        def run(pipelined):
+            stats = {}
+            t0 = time.perf_counter()
+            m, errs = featurize_audio_jobs_device(jobs, feature_flags=FLAGS, audio_read_config=cfg, workers=threads,
+                                                  pipelined=pipelined, stats=stats)
+            host = m.to(torch.float64).cpu().numpy()
+            dt = time.perf_counter() - t0
+            assert not any(errs) and np.isfinite(host).all()
+            return dt, host, stats
+        run(True)     # staging buffers, plans, page cache
+        seq = min(run(False)[0] for _ in range(2))
+        pip_runs = [run(True) for _ in range(3)]
+        pip = min(r[0] for r in pip_runs)
+        host, stats = pip_runs[-1][1], pip_runs[-1][2]
+        bound = min(out["reader_only"]["audio_seconds_per_s"], out["h2d_pinned"]["audio_seconds_per_s"],
+                    out["kernels_only"]["audio_seconds_per_s"])
+        out["sequential"] = {"s": seq, "audio_seconds_per_s": sec / seq}
+        out["pipelined"] = {"s": pip, "audio_seconds_per_s": sec / pip, "stats": stats}
+        out["bound"] = {"audio_seconds_per_s": bound,
+                        "which": min(("reader_only", "h2d_pinned", "kernels_only"), key=lambda k: out[k]["audio_seconds_per_s"])}
+        out["pipelined_frac_of_bound"] = (sec / pip) / bound
+        # ---- the cache the reference's trainer consumes (np.savez_compressed, float64): reported beside, not inside
+        t0 = time.perf_counter()
+        cut = n * 3 // 4
+        path = write_prepared_feature_payload(root / "tmp" / "prepared-training-fast.npz", x_train=host[:cut], x_dev=host[:0],
+                                              x_test=host[cut:], y_train=labels[:cut], y_dev=[], y_test=labels[cut:],
+                                              metadata={"cache_namespace": "fast_features", "feature_dim": 187})
+        out["cache_write"] = {"s": time.perf_counter() - t0, "bytes": path.stat().st_size}
+        res["config2_from_files"] = out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def config3_from_host(eng, res):
+    """One GPU's shard of config 3 (12 500 x 3 s float32) starting in pageable numpy memory."""
+    from ser_amd import ingest
+
+    n, length = 12500, 48000
+    audio = harmonic_clips_torch(1234, n, length, eng.device).reshape(-1).cpu().numpy()
+    offs = np.arange(n, dtype=np.int64) * length
+    lens = np.full(n, length, dtype=np.int64)
+    sec = n * 3.0
+    threads = ingest.host_threads()
+    out = {"what": f"{n} clips x 3 s float32 in pageable host memory ({audio.nbytes / 1e9:.2f} GB) -> [n, 187] on the device",
+           "host_threads": threads}
+    pin = torch.empty(256 << 20, dtype=torch.uint8, pin_memory=True)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for k in range(4):
+            ingest.parallel_memcpy(pin.data_ptr(), audio.ctypes.data + k * pin.numel(), pin.numel(), threads)
+        best = min(best, time.perf_counter() - t0)
+    out["staging_memcpy"] = {"GBps": 4 * pin.numel() / best / 1e9, "audio_seconds_per_s": sec / (audio.nbytes / (4 * pin.numel() / best))}
+    del pin
+    gbps = h2d_rate(eng)
+    out["h2d_pinned"] = {"GBps": gbps, "audio_seconds_per_s": sec / (audio.nbytes / (gbps * 1e9))}
+    dev = torch.from_numpy(audio[: 2500 * length]).to(eng.device)
+    dt, _ = timed(lambda: eng.features(dev, offs[:2500], lens[:2500], SR, FLAGS), 5)
+    out["kernels_only"] = {"audio_seconds_per_s": 2500 * 3.0 / dt}
+    del dev
+
+    def old():
+        return eng.features(torch.from_numpy(audio).to(eng.device), offs, lens, SR, FLAGS)
+    dt_old, want = timed(old, 2)
+    stats = {}
+    ingest.features_from_host(eng, audio, offs, lens, SR, FLAGS, stats=stats)
+    dt_new, got = timed(lambda: eng.features(audio, offs, lens, SR, FLAGS), 3)
+    assert torch.equal(want, got)
+    bound = min(out[k]["audio_seconds_per_s"] for k in ("staging_memcpy", "h2d_pinned", "kernels_only"))
+    out["whole_buffer_copy_then_compute"] = {"s": dt_old, "audio_seconds_per_s": sec / dt_old}
+    out["pipelined"] = {"s": dt_new, "audio_seconds_per_s": sec / dt_new, "stats": stats}
+    out["bound"] = {"audio_seconds_per_s": bound,
+                    "which": min(("staging_memcpy", "h2d_pinned", "kernels_only"), key=lambda k: out[k]["audio_seconds_per_s"])}
+    out["pipelined_frac_of_bound"] = (sec / dt_new) / bound
+    res["config3_from_host"] = out
+
+
+CONFIGS = {"config1": config1, "config2_scaled": config2_scaled, "config4": config4, "config5": config5,
+           "generic_short": generic_short, "config2_from_files": config2_from_files, "config3_from_host": config3_from_host}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma-separated subset of: " + ", ".join(CONFIGS))
+    args = ap.parse_args()
+    names = [n for n in args.only.split(",") if n] or list(CONFIGS)
+    eng = get_engine()
+    res = {}
+    for name in names:
+        CONFIGS[name](eng, res)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        print(f"[bench_configs] {name} done", file=sys.stderr, flush=True)
     print(json.dumps(res, indent=1))
 
 

@@ -57,6 +57,13 @@ SIGNATURES: dict[str, tuple] = {
     "serhip_comm_destroy": (None, [c_void_p]),
     "serhip_profile_enable": (c_int, [c_void_p, c_int]),
     "serhip_profile_read": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
+    "serhip_read_wav_batch": (
+        c_int,
+        [c_void_p, POINTER(c_int64), c_int64, c_void_p, c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p, c_int64,
+         c_int, c_void_p],
+    ),
+    "serhip_stat_files": (c_int, [c_void_p, POINTER(c_int64), c_int64, c_int, POINTER(c_int64)]),
+    "serhip_parallel_memcpy": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
     "serhip_host_table": (c_int64, [c_int, c_int, c_int, POINTER(c_float), c_int64]),
     "serhip_frame_count": (c_int64, [c_int64]),
 }

@@ -36,6 +36,7 @@ typedef enum { ncclFloat32 = 7 } ncclDataType_t;
 #include "kernels_project.hpp"
 #include "kernels_whisper.hpp"
 #include "tables.hpp"
+#include "wav_reader.hpp"
 
 using namespace serhip;
 
@@ -201,8 +202,16 @@ struct serhip_ctx {
     int device = 0;
     void* ws = nullptr;          // device workspace (scratch + descriptors)
     size_t ws_bytes = 0;
-    void* staging = nullptr;     // pinned host staging for descriptors
-    size_t staging_bytes = 0;
+    // pinned host staging for descriptors: a ring of slots, each with the event of the upload that last read it.
+    // A call takes the next slot and waits for THAT slot's event -- recorded kStagingSlots uploads ago -- so a
+    // stream of calls (the slab pipeline: prepare + features per slab) never waits on the host for the upload it
+    // has just enqueued behind a long H2D copy.  `staging` / `staging_done` name the slot of the current call.
+    static constexpr int kStagingSlots = 4;
+    void* st_buf[kStagingSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t st_bytes[kStagingSlots] = {0, 0, 0, 0};
+    hipEvent_t st_done[kStagingSlots] = {nullptr, nullptr, nullptr, nullptr};
+    int st_next = 0;
+    void* staging = nullptr;
     hipEvent_t staging_done = nullptr;
     // the workspace is shared by every call on the context: the last user's stream, and the event a call on
     // another stream records there and waits for (WorkspaceUse)
@@ -302,14 +311,19 @@ struct WorkspaceUse {
 };
 
 int ensure_staging(serhip_ctx* ctx, size_t bytes) {
-    if (ctx->staging_done) HIP_TRY(hipEventSynchronize(ctx->staging_done));
-    if (bytes <= ctx->staging_bytes) return SERHIP_OK;
-    if (ctx->staging) HIP_TRY(hipHostFree(ctx->staging));
-    ctx->staging = nullptr;
-    ctx->staging_bytes = 0;
-    const size_t want = align_up(bytes * 2, 4096);
-    HIP_TRY(hipHostMalloc(&ctx->staging, want, hipHostMallocDefault));
-    ctx->staging_bytes = want;
+    const int slot = ctx->st_next;
+    ctx->st_next = (slot + 1) % serhip_ctx::kStagingSlots;
+    HIP_TRY(hipEventSynchronize(ctx->st_done[slot]));   // the upload that read this slot last (an unrecorded event is complete)
+    if (bytes > ctx->st_bytes[slot]) {
+        if (ctx->st_buf[slot]) HIP_TRY(hipHostFree(ctx->st_buf[slot]));
+        ctx->st_buf[slot] = nullptr;
+        ctx->st_bytes[slot] = 0;
+        const size_t want = align_up(bytes * 2, 4096);
+        HIP_TRY(hipHostMalloc(&ctx->st_buf[slot], want, hipHostMallocDefault));
+        ctx->st_bytes[slot] = want;
+    }
+    ctx->staging = ctx->st_buf[slot];
+    ctx->staging_done = ctx->st_done[slot];
     return SERHIP_OK;
 }
 
@@ -756,11 +770,18 @@ int serhip_create(int device_id, serhip_ctx** out) {
     HIP_TRY(hipSetDevice(device_id));
     serhip_ctx* ctx = new serhip_ctx();
     ctx->device = device_id;
-    if (hipEventCreateWithFlags(&ctx->staging_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ws_done, hipEventDisableTiming) != hipSuccess) {
-        if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
-        delete ctx;
-        return fail(SERHIP_E_HIP, "serhip_create: hipEventCreate failed");
+    {
+        bool ok = hipEventCreateWithFlags(&ctx->ws_done, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < serhip_ctx::kStagingSlots; ++i)
+            ok = hipEventCreateWithFlags(&ctx->st_done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            for (hipEvent_t e : ctx->st_done)
+                if (e) (void)hipEventDestroy(e);
+            if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
+            delete ctx;
+            return fail(SERHIP_E_HIP, "serhip_create: hipEventCreate failed");
+        }
     }
     {
         int cus = 0;
@@ -802,11 +823,13 @@ void serhip_destroy(serhip_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     for (void* b : ctx->whisper_blob)
         if (b) (void)hipFree(b);
-    if (ctx->staging) (void)hipHostFree(ctx->staging);
+    for (void* b : ctx->st_buf)
+        if (b) (void)hipHostFree(b);
     if (ctx->na_staging) (void)hipHostFree(ctx->na_staging);
     if (ctx->na_staging_done) (void)hipEventDestroy(ctx->na_staging_done);
     if (ctx->na_done) (void)hipEventDestroy(ctx->na_done);
-    if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
+    for (hipEvent_t e : ctx->st_done)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
     for (const serhip_ctx::Timed& t : ctx->timed) {
         (void)hipEventDestroy(t.start);
@@ -1459,6 +1482,50 @@ int serhip_profile_read(serhip_ctx* ctx, int kind, double* total_ms, int64_t* la
     ctx->timed.swap(keep);
     *total_ms = sum;
     *launches = n;
+    return SERHIP_OK;
+}
+
+int serhip_read_wav_batch(const char* paths_blob, const int64_t* path_offset, int64_t n_files, const double* start_seconds,
+                          const double* duration_seconds, const int64_t* dst_offset, const int64_t* dst_capacity, void* dst,
+                          int64_t dst_bytes, int threads, serhip_wav_clip* clips) {
+    if (n_files < 0) return fail(SERHIP_E_INVALID, "serhip_read_wav_batch: n_files < 0");
+    if (n_files == 0) return SERHIP_OK;
+    if (!paths_blob || !path_offset || !dst_offset || !dst_capacity || !dst || !clips)
+        return fail(SERHIP_E_INVALID, "serhip_read_wav_batch: NULL argument");
+    for (int64_t i = 0; i < n_files; ++i)
+        if (dst_offset[i] < 0 || dst_capacity[i] < 0 || dst_offset[i] > dst_bytes - dst_capacity[i])
+            return fail(SERHIP_E_INVALID, "serhip_read_wav_batch: region of file " + std::to_string(i) + " lies outside dst");
+    unsigned char* slab = static_cast<unsigned char*>(dst);
+    parallel_for(n_files, threads, [&](int64_t i) {
+        serhip_wav_clip c{};
+        c.status = read_one_wav(paths_blob + path_offset[i], start_seconds ? start_seconds[i] : NAN,
+                                duration_seconds ? duration_seconds[i] : NAN, slab, dst_offset[i], dst_capacity[i], &c);
+        clips[i] = c;
+    });
+    return SERHIP_OK;
+}
+
+int serhip_stat_files(const char* paths_blob, const int64_t* path_offset, int64_t n_files, int threads, int64_t* sizes) {
+    if (n_files < 0) return fail(SERHIP_E_INVALID, "serhip_stat_files: n_files < 0");
+    if (n_files == 0) return SERHIP_OK;
+    if (!paths_blob || !path_offset || !sizes) return fail(SERHIP_E_INVALID, "serhip_stat_files: NULL argument");
+    parallel_for(n_files, threads, [&](int64_t i) {
+        struct stat st;
+        sizes[i] = (::stat(paths_blob + path_offset[i], &st) == 0 && S_ISREG(st.st_mode)) ? static_cast<int64_t>(st.st_size) : -1;
+    });
+    return SERHIP_OK;
+}
+
+int serhip_parallel_memcpy(void* dst, const void* src, int64_t bytes, int threads) {
+    if (bytes < 0) return fail(SERHIP_E_INVALID, "serhip_parallel_memcpy: bytes < 0");
+    if (bytes == 0) return SERHIP_OK;
+    if (!dst || !src) return fail(SERHIP_E_INVALID, "serhip_parallel_memcpy: NULL argument");
+    const int64_t piece = 4 << 20;   // 4 MiB pieces drawn from a counter
+    const int64_t n = (bytes + piece - 1) / piece;
+    parallel_for(n, threads, [&](int64_t i) {
+        const int64_t at = i * piece;
+        std::memcpy(static_cast<char*>(dst) + at, static_cast<const char*>(src) + at, static_cast<size_t>(std::min(piece, bytes - at)));
+    });
     return SERHIP_OK;
 }
 

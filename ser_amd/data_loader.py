@@ -246,13 +246,34 @@ def _job_slabs(jobs, budget: int):
         yield first, len(jobs)
 
 
+def _is_batch_fatal(err: Exception) -> bool:
+    """Errors that halving a batch cannot cure and that must not be dressed up as per-file failures: a HIP runtime
+    failure reported by the library (``SERHIP_E_HIP``; after a device fault every later call fails the same way),
+    torch's own "HIP error", and configuration errors such as the tonnetz refusal.  Out-of-memory IS size-dependent
+    and validation errors ARE per clip: those bisect."""
+    from ._native import SerhipError
+
+    if isinstance(err, SerhipError):
+        return err.code == -2
+    if isinstance(err, NotImplementedError):
+        return True
+    if isinstance(err, RuntimeError) and "out of memory" not in str(err).lower():
+        text = str(err)
+        return "HIP error" in text or "hipError" in text or "no CPU fallback" in text
+    return False
+
+
 def _bisecting(indices: list[int], run, on_error) -> None:
     """``run(indices)`` for the whole group; when that raises, halve the group and try again, down to
     single items, so that one bad clip (or one batch too large for HBM) costs only itself: the
-    reference loses exactly the offending file (data_loader.py:296-297), not its neighbours."""
+    reference loses exactly the offending file (data_loader.py:296-297), not its neighbours.  Device and
+    configuration errors (:func:`_is_batch_fatal`) are raised at once instead: re-running them clip by clip
+    would cost O(n) GPU batches and turn one device fault into n "bad files"."""
     try:
         run(indices)
     except Exception as err:
+        if _is_batch_fatal(err):
+            raise
         if len(indices) == 1:
             on_error(indices[0], err)
             return
@@ -266,10 +287,8 @@ def _featurize_raw_group(clips, rate: int, sample_format: str, feature_flags: Fe
     back to back (16-byte aligned), converted / mixed down / peak-normalised on the device
     (``serhip_prepare_audio``) and featurised from there -- the samples never exist on the host.
     Returns the ``[len(clips), D]`` float32 DEVICE tensor."""
-    from . import dsp
     from .engine import get_engine
 
-    dsp.check_flags_for_rate(feature_flags, rate)
     offsets, cursor = [], 0
     for clip in clips:
         offsets.append(cursor)
@@ -285,21 +304,37 @@ def _featurize_raw_group(clips, rate: int, sample_format: str, feature_flags: Fe
 
 def _featurize_host_group(clips, rate: int, feature_flags: FeatureFlags):
     """One GPU batch for clips decoded and prepared on the host; ``[len(clips), D]`` float32 device tensor."""
-    from . import dsp
     from .engine import get_engine
 
-    dsp.check_flags_for_rate(feature_flags, rate)
     lengths = np.asarray([c.size for c in clips], dtype=np.int64)
     offsets = np.concatenate(([0], np.cumsum(lengths)[:-1])).astype(np.int64)
     return get_engine().features(np.concatenate(clips), offsets, lengths, rate, feature_flags)
 
 
+def _group_config_error(feature_flags: FeatureFlags, rate: int) -> Exception | None:
+    """The error every clip of a sample rate gets when the flags cannot be computed at that rate (the reference's
+    spectral_contrast raises for sr <= 12 800): a property of the group, so no GPU batch and no retries."""
+    from . import dsp
+
+    try:
+        dsp.check_flags_for_rate(feature_flags, rate)
+    except Exception as err:
+        return err
+    return None
+
+
 def featurize_audio_jobs_device(jobs: Sequence[tuple[str, float | None, float | None]], *,
                                 feature_flags: FeatureFlags, audio_read_config: AudioReadConfig, workers: int = 8,
-                                device_prepare: bool = True):
+                                device_prepare: bool = True, pipelined: bool | None = None, stats: dict | None = None):
     """Device-resident form of :func:`featurize_audio_jobs`: ``(matrix, errors)`` with ``matrix`` a
     ``[n_jobs, D]`` float32 torch tensor on the engine's GPU (failed rows NaN).  The multi-GPU gather
-    takes this tensor as it is -- features never visit the host on their way into the collective."""
+    takes this tensor as it is -- features never visit the host on their way into the collective.
+
+    ``pipelined`` (default: on with ``device_prepare``, off with ``SERHIP_INGEST=sequential``): files are read by
+    ``workers`` native threads straight into pinned memory one slab ahead, each slab's raw bytes travel on a copy
+    stream while the previous slab's kernels run (``ser_amd.ingest``) -- the GPU form of the overlap the reference
+    gets from ``Pool.imap_unordered`` (data_loader.py:368-379).  Results are bit-identical to the sequential form
+    (read a slab, pack, copy, compute, repeat), which remains for comparison and for ``device_prepare=False``."""
     from .engine import get_engine
 
     require_accelerated(feature_flags)
@@ -311,9 +346,34 @@ def featurize_audio_jobs_device(jobs: Sequence[tuple[str, float | None, float | 
     errors: list[Exception | None] = [None] * n
     if n == 0 or dim == 0:
         return matrix, errors
+    if pipelined is None:
+        pipelined = device_prepare and os.environ.get("SERHIP_INGEST", "pipelined") != "sequential"
 
     def fail(i: int, err: Exception) -> None:
         errors[i] = err
+
+    def run_host_members(lo: int, rate: int, members) -> None:
+        """members: [(index relative to lo, prepared float32 samples)] of one sample rate"""
+        err = _group_config_error(feature_flags, rate)
+        if err is not None:
+            for i, _ in members:
+                errors[lo + i] = err
+            return
+        by_index = dict(members)
+
+        def run_host(sub):
+            rows = _featurize_host_group([by_index[i] for i in sub], rate, feature_flags)
+            matrix[torch.as_tensor([lo + i for i in sub], device=engine.device)] = rows
+        _bisecting([i for i, _ in members], run_host, lambda i, e: fail(lo + i, e))
+
+    if pipelined:
+        from .ingest import featurize_jobs_pipelined
+
+        featurize_jobs_pipelined(
+            jobs, feature_flags=feature_flags, audio_read_config=audio_read_config, workers=workers, matrix=matrix,
+            errors=errors, read_fallback=lambda job: _read_one((*job, audio_read_config, False)),
+            run_host_group=run_host_members, bisect=_bisecting, stats=stats)
+        return matrix, errors
 
     for lo, hi in _job_slabs(jobs, _slab_bytes()):
         packed = [(p, s, d, audio_read_config, device_prepare) for p, s, d in jobs[lo:hi]]
@@ -323,7 +383,7 @@ def featurize_audio_jobs_device(jobs: Sequence[tuple[str, float | None, float | 
         else:
             decoded = [_read_one(j) for j in packed]
         raw_groups: dict[tuple[int, str], list[int]] = {}
-        host_groups: dict[int, list[int]] = {}
+        host_groups: dict[int, list[tuple[int, np.ndarray]]] = {}
         for k, (kind, value, err) in enumerate(decoded):
             if kind is None:
                 errors[lo + k] = err
@@ -334,19 +394,22 @@ def featurize_audio_jobs_device(jobs: Sequence[tuple[str, float | None, float | 
                     from .dsp import validate_signal
 
                     validate_signal(value[0], int(value[1]))
-                    host_groups.setdefault(int(value[1]), []).append(k)
+                    host_groups.setdefault(int(value[1]), []).append((k, value[0]))
                 except Exception as err2:
                     errors[lo + k] = err2
         for (rate, sample_format), ks in raw_groups.items():
+            err = _group_config_error(feature_flags, rate)
+            if err is not None:
+                for k in ks:
+                    errors[lo + k] = err
+                continue
+
             def run_raw(sub, rate=rate, sample_format=sample_format):
                 rows = _featurize_raw_group([decoded[k][1] for k in sub], rate, sample_format, feature_flags)
                 matrix[torch.as_tensor([lo + k for k in sub], device=engine.device)] = rows
             _bisecting(ks, run_raw, lambda k, err: fail(lo + k, err))
-        for rate, ks in host_groups.items():
-            def run_host(sub, rate=rate):
-                rows = _featurize_host_group([decoded[k][1][0] for k in sub], rate, feature_flags)
-                matrix[torch.as_tensor([lo + k for k in sub], device=engine.device)] = rows
-            _bisecting(ks, run_host, lambda k, err: fail(lo + k, err))
+        for rate, members in host_groups.items():
+            run_host_members(lo, rate, members)
         del decoded
     return matrix, errors
 
@@ -367,7 +430,10 @@ def featurize_audio_jobs(jobs: Sequence[tuple[str, float | None, float | None]],
     matrix, errors = featurize_audio_jobs_device(jobs, feature_flags=feature_flags,
                                                  audio_read_config=audio_read_config, workers=workers,
                                                  device_prepare=device_prepare)
-    return matrix.cpu().numpy().astype(np.float64), errors
+    # widened on the device (exact), so that the host sees the API's float64 without a pass of its own
+    import torch
+
+    return matrix.to(torch.float64).cpu().numpy(), errors
 
 
 def featurize_files(files: Sequence[str], *, settings=None, distributed: bool = False, featurize_jobs=None):
@@ -389,7 +455,9 @@ def featurize_files(files: Sequence[str], *, settings=None, distributed: bool = 
         matrix, errors = run([(f, None, None) for f in files], feature_flags=active.feature_flags,
                              audio_read_config=active.audio_read, workers=workers)
         if hasattr(matrix, "cpu"):
-            matrix = matrix.cpu().numpy()
+            import torch
+
+            matrix = matrix.to(torch.float64).cpu().numpy()   # widened on the device: exact, and no host pass
         return np.asarray(matrix, dtype=np.float64), errors
     import torch
     import torch.distributed as dist

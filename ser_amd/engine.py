@@ -111,27 +111,43 @@ class FeatureEngine:
             )
         return out
 
+    #: host buffers at least this large go to the GPU through the staged, overlapped path (ser_amd.ingest)
+    STREAM_FROM_HOST_BYTES = 32 << 20
+
     def features(self, audio, seg_offset, seg_len, sample_rate: int, flags: FeatureFlags, *,
-                 return_tuning: bool = False):
+                 return_tuning: bool = False, out=None):
         """Feature matrix ``[n_seg, D]`` (float32, on device) for segments of ``audio``.
 
         ``audio`` is a 1-D float32 numpy array or torch tensor (moved to the GPU if
-        needed); ``seg_offset`` / ``seg_len`` are host integer sequences.
+        needed); ``seg_offset`` / ``seg_len`` are host integer sequences.  ``out`` may name the
+        contiguous float32 ``[n_seg, D]`` device tensor (e.g. a row range of a larger matrix) the kernels
+        write into.  A large numpy buffer whose segments come in non-decreasing order is not copied whole
+        first: it is staged chunk by chunk while the kernels run (``ingest.features_from_host``).
         """
         require_accelerated(flags)
         torch = self._torch
-        audio_dev = self.to_device(audio)
-        if audio_dev.dim() != 1:
-            raise ValueError("audio must be a 1-D sample buffer")
         off = _as_i64(seg_offset)
         length = _as_i64(seg_len)
         if off.shape != length.shape or off.ndim != 1:
             raise ValueError("seg_offset and seg_len must be 1-D and the same length")
         n_seg = int(off.shape[0])
         dim = flags.width()
+        if out is not None and (not isinstance(out, torch.Tensor) or out.device != self.device or out.dtype != torch.float32
+                                or not out.is_contiguous() or tuple(out.shape) != (n_seg, dim)):
+            raise ValueError(f"out must be a contiguous float32 ({n_seg}, {dim}) tensor on {self.device}")
+        if (not return_tuning and isinstance(audio, np.ndarray) and audio.ndim == 1 and n_seg > 1
+                and audio.nbytes >= self.STREAM_FROM_HOST_BYTES and os.environ.get("SERHIP_INGEST", "pipelined") != "sequential"
+                and bool((np.diff(off) >= 0).all())):
+            from .ingest import features_from_host
+
+            return features_from_host(self, audio, off, length, int(sample_rate), flags, out=out)
+        audio_dev = self.to_device(audio)
+        if audio_dev.dim() != 1:
+            raise ValueError("audio must be a 1-D sample buffer")
         with self._torch.cuda.device(self.device), self._lock:
             plan = self._ctx.plan(int(sample_rate), flags.native_bits())
-            out = torch.empty((n_seg, dim), dtype=torch.float32, device=self.device)
+            if out is None:
+                out = torch.empty((n_seg, dim), dtype=torch.float32, device=self.device)
             tuning = torch.empty((n_seg,), dtype=torch.float32, device=self.device) if return_tuning else None
             if n_seg and dim:
                 _native.check(

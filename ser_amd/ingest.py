@@ -1,0 +1,421 @@
+"""Overlapped ingest: files and host buffers on their way into the feature kernels.
+
+The reference hides decoding behind feature extraction with a ``multiprocessing.Pool`` whose workers each
+read AND featurise one file at a time (``ser/_internal/data/data_loader.py:368-379``,
+``imap_unordered(process_file, files, chunksize=...)``).  With the features on a GPU the same overlap is
+a three-stage pipeline over *slabs* of files:
+
+    reader threads (native, ``serhip_read_wav_batch``)   slab k+1 .. k+2  -> pinned host memory
+    copy stream (one asynchronous H2D per slab)          slab k           -> HBM, raw bytes (2 B/sample for PCM16)
+    compute stream (``serhip_prepare_audio`` + ``serhip_fast_features``)  slab k-1
+
+Nothing on the host touches a sample: files are read straight into pinned memory, headers parsed in place,
+conversion / mix-down / scrub / peak normalisation happen on the device.  Everything the native reader does
+not take (other encodings, LFS pointers, missing files ...) goes through ``audio_io`` exactly as before, so
+errors and retries are the reference's.
+
+``features_from_host`` is the same idea for callers that hold decoded float32 audio in ordinary (pageable)
+numpy memory: chunks are staged into pinned buffers by a team of memcpy threads, copied on the copy stream,
+and featurised while the next chunk is staged.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+from ctypes import POINTER, c_int64, c_void_p
+
+import numpy as np
+
+from . import _native
+
+#: mirror of ``serhip_wav_clip`` (include/serhip.h)
+WAV_CLIP_DTYPE = np.dtype([("raw_offset", "<i8"), ("frames", "<i8"), ("sample_rate", "<i4"), ("channels", "<i4"),
+                           ("sample_format", "<i4"), ("status", "<i4")], align=True)
+WAV_OK = 0
+SAMPLE_FORMAT_NAMES = {0: "s16", 1: "f32"}
+
+DEFAULT_SLAB_BYTES = 128 << 20     # file bytes per slab (override: SERHIP_SLAB_BYTES)
+DEFAULT_CHUNK_BYTES = 64 << 20     # host-buffer bytes per staged chunk (override: SERHIP_CHUNK_BYTES)
+PINNED_BUFFERS = 3                 # one being read into, one in flight to the GPU, one spare
+DEVICE_BUFFERS = 2                 # one being copied into, one being read by the kernels
+
+
+def host_threads(requested: int | None = None) -> int:
+    """Threads for the native reader / memcpy teams: the caller's number, else ``SERHIP_INGEST_THREADS``, else the
+    cores this process may use, capped at 16 (a one-GPU share of the box; ``os.cpu_count()`` shows the whole
+    machine there)."""
+    if requested is not None and requested > 0:
+        return int(requested)
+    env = os.environ.get("SERHIP_INGEST_THREADS")
+    if env:
+        try:
+            return max(1, int(env))
+        except ValueError:
+            pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        avail = os.cpu_count() or 1
+    return max(1, min(16, avail))
+
+
+def _env_bytes(name: str, default: int) -> int:
+    try:
+        return max(1 << 20, int(os.environ.get(name, default)))
+    except ValueError:
+        return default
+
+
+def encode_paths(paths) -> tuple[bytes, np.ndarray]:
+    """``(blob, offsets)``: the paths NUL-terminated back to back, and where each one starts.  Built ONCE per call of
+    the loader and shared by the stat pass and every slab's read (a slab passes a slice of ``offsets``): per-file
+    Python work is what a 100k-file corpus cannot afford."""
+    n = len(paths)
+    if n and all(isinstance(p, str) for p in paths):
+        try:
+            blob = ("\0".join(paths) + "\0").encode("utf-8", "surrogateescape")   # what os.fsencode does on Linux
+        except UnicodeError:
+            blob = None
+        if blob is not None and blob.isascii():   # then character counts are byte counts
+            lengths = np.fromiter(map(len, paths), dtype=np.int64, count=n) + 1
+            offsets = np.zeros(n, dtype=np.int64)
+            np.cumsum(lengths[:-1], out=offsets[1:])
+            return blob, offsets
+    encoded = [os.fsencode(p) for p in paths]
+    lengths = np.fromiter((len(e) + 1 for e in encoded), dtype=np.int64, count=n)
+    offsets = np.zeros(n, dtype=np.int64)
+    if n > 1:
+        np.cumsum(lengths[:-1], out=offsets[1:])
+    return b"\0".join(encoded) + b"\0", offsets
+
+
+def stat_files(paths, threads: int | None = None, *, table=None) -> np.ndarray:
+    """File sizes in bytes (-1: missing or not a regular file), one native call for the whole list."""
+    lib = _native.load_library()
+    blob, offsets = table if table is not None else encode_paths(paths)
+    sizes = np.empty(len(offsets), dtype=np.int64)
+    if len(offsets):
+        _native.check(lib.serhip_stat_files(blob, offsets.ctypes.data_as(POINTER(c_int64)), len(offsets),
+                                            host_threads(threads), sizes.ctypes.data_as(POINTER(c_int64))))
+    return sizes
+
+
+def read_wav_batch(paths, dst_ptr: int, dst_bytes: int, dst_offset: np.ndarray, dst_capacity: np.ndarray, *,
+                   start_seconds=None, duration_seconds=None, threads: int | None = None, table=None) -> np.ndarray:
+    """Read whole files into their regions of the host buffer at ``dst_ptr`` (``serhip_read_wav_batch``).
+    Returns the per-file records (:data:`WAV_CLIP_DTYPE`); ``status != 0`` means "use the Python reader".
+    ``table`` = ``(blob, offsets)`` of :func:`encode_paths` (offsets may be a slice of a larger table) replaces ``paths``."""
+    lib = _native.load_library()
+    blob, offsets = table if table is not None else encode_paths(paths)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets)
+    clips = np.zeros(n, dtype=WAV_CLIP_DTYPE)
+    if n == 0:
+        return clips
+    dst_offset = np.ascontiguousarray(dst_offset, dtype=np.int64)
+    dst_capacity = np.ascontiguousarray(dst_capacity, dtype=np.int64)
+
+    def seconds(values):
+        if values is None:
+            return None, None
+        arr = np.ascontiguousarray([np.nan if v is None else float(v) for v in values], dtype=np.float64)
+        return arr, arr.ctypes.data_as(c_void_p)
+
+    s_arr, s_ptr = seconds(start_seconds)
+    d_arr, d_ptr = seconds(duration_seconds)
+    _native.check(lib.serhip_read_wav_batch(blob, offsets.ctypes.data_as(POINTER(c_int64)), n, s_ptr, d_ptr,
+                                            dst_offset.ctypes.data_as(POINTER(c_int64)),
+                                            dst_capacity.ctypes.data_as(POINTER(c_int64)), c_void_p(int(dst_ptr)),
+                                            int(dst_bytes), host_threads(threads), clips.ctypes.data_as(c_void_p)))
+    del s_arr, d_arr
+    return clips
+
+
+def parallel_memcpy(dst_ptr: int, src_ptr: int, nbytes: int, threads: int | None = None) -> None:
+    _native.check(_native.load_library().serhip_parallel_memcpy(c_void_p(int(dst_ptr)), c_void_p(int(src_ptr)),
+                                                                int(nbytes), host_threads(threads)))
+
+
+def plan_slabs(sizes: np.ndarray, slab_bytes: int) -> list[tuple[int, int]]:
+    """Cut ``range(len(sizes))`` into consecutive ``[lo, hi)`` slabs whose 16-byte-aligned file sizes add up to at
+    most ``slab_bytes`` (a single larger file gets a slab of its own).  Missing files (-1) take no room: they fail
+    when read."""
+    room = (np.maximum(sizes, 0) + 15) // 16 * 16
+    ends = np.cumsum(room)
+    slabs, lo, base, n = [], 0, 0, len(sizes)
+    while lo < n:
+        hi = int(np.searchsorted(ends, base + slab_bytes, side="right"))
+        hi = max(hi, lo + 1)
+        slabs.append((lo, hi))
+        base = int(ends[hi - 1])
+        lo = hi
+    return slabs
+
+
+class IngestBuffers:
+    """Per-engine staging, created on first use and kept: pinned host buffers, device buffers for the raw bytes, the
+    copy stream, and the event after which the device buffers are free again (the previous call's kernels)."""
+
+    def __init__(self, engine) -> None:
+        self.engine = engine
+        self.torch = engine._torch
+        self.copy_stream = self.torch.cuda.Stream(device=engine.device)
+        self.pinned: list = []
+        self.device: list = []
+        self.last_use = None     # event on the compute stream: everything that read self.device has been enqueued before it
+
+    def ensure(self, nbytes: int) -> None:
+        torch = self.torch
+        nbytes = (int(nbytes) + 4095) // 4096 * 4096
+        if self.pinned and self.pinned[0].numel() >= nbytes:
+            return
+        if self.last_use is not None:
+            self.last_use.synchronize()
+        self.copy_stream.synchronize()
+        self.pinned = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(PINNED_BUFFERS)]
+        self.device = [torch.empty(nbytes, dtype=torch.uint8, device=self.engine.device) for _ in range(DEVICE_BUFFERS)]
+
+
+def ingest_buffers(engine) -> IngestBuffers:
+    buf = getattr(engine, "_ingest_buffers", None)
+    if buf is None:
+        buf = IngestBuffers(engine)
+        engine._ingest_buffers = buf
+    return buf
+
+
+class _Stage:
+    """Bookkeeping shared by the two pipelines: which pinned / device buffer a step uses and the events that guard them."""
+
+    def __init__(self, engine, nbytes: int) -> None:
+        self.engine = engine
+        self.torch = engine._torch
+        self.buffers = ingest_buffers(engine)
+        self.buffers.ensure(nbytes)
+        self.copied: dict[int, object] = {}   # step -> event on the copy stream: its H2D has finished
+        self.done: dict[int, object] = {}     # step -> event on the compute stream: its kernels have been enqueued before it
+        self.compute = self.torch.cuda.current_stream(engine.device)
+
+    def pinned(self, k: int):
+        return self.buffers.pinned[k % PINNED_BUFFERS]
+
+    def wait_pinned_free(self, k: int) -> None:
+        """Host-side: the copy that last read pinned buffer ``k % PINNED_BUFFERS`` has finished (called by the thread
+        that is about to overwrite it)."""
+        prev = self.copied.get(k - PINNED_BUFFERS)
+        if prev is not None:
+            prev.synchronize()
+
+    def upload(self, k: int, used: int):
+        """Enqueue the H2D of step ``k`` on the copy stream; returns the device view of its bytes.  The compute stream
+        is made to wait for it."""
+        torch, buf = self.torch, self.buffers
+        dev = buf.device[k % DEVICE_BUFFERS]
+        copy = buf.copy_stream
+        guard = self.done.get(k - DEVICE_BUFFERS, buf.last_use if k < DEVICE_BUFFERS else None)
+        with torch.cuda.stream(copy):
+            if guard is not None:
+                copy.wait_event(guard)   # the kernels that read this device buffer last
+            if used:
+                dev[:used].copy_(self.pinned(k)[:used], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy)
+        self.copied[k] = ev
+        self.compute.wait_event(ev)
+        return dev[:used]
+
+    def computed(self, k: int) -> None:
+        ev = self.torch.cuda.Event()
+        ev.record(self.compute)
+        self.done[k] = ev
+        self.buffers.last_use = ev
+        self.copied.pop(k - 2 * PINNED_BUFFERS, None)
+        self.done.pop(k - 2 * DEVICE_BUFFERS, None)
+
+    def finish(self) -> None:
+        """All copies out of the pinned buffers have finished (they are about to be reused by the next call)."""
+        self.buffers.copy_stream.synchronize()
+
+
+# ------------------------------------------------------------------------------------------ files -> features
+def featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers: int, matrix, errors,
+                             read_fallback, run_host_group, bisect, stats: dict | None = None) -> None:
+    """Fill ``matrix`` (``[n_jobs, D]`` float32 device tensor) and ``errors`` for ``jobs`` with reading, copying and
+    computing overlapped slab by slab.  The caller (``data_loader.featurize_audio_jobs_device``) supplies the pieces
+    that are not specific to the pipeline: ``read_fallback(job)`` (the Python reader), ``run_host_group`` (host-decoded
+    clips of one rate) and ``bisect`` (its failure-isolating retry)."""
+    from . import dsp
+    from .engine import get_engine
+
+    import time
+
+    t_enter = time.perf_counter()
+    engine = get_engine()
+    torch = engine._torch
+    n = len(jobs)
+    paths, job_starts, job_durations = (list(column) for column in zip(*jobs))   # one C-level pass over 100k tuples
+    any_segment = job_starts.count(None) != n or job_durations.count(None) != n
+    blob, path_at = encode_paths(paths)
+    sizes = stat_files(None, workers, table=(blob, path_at))
+    total = int(np.maximum(sizes, 0).sum())
+    slab_bytes = _env_bytes("SERHIP_SLAB_BYTES", DEFAULT_SLAB_BYTES)
+    # ~32 slabs when the corpus is large enough to make pipelining worth it: the first read and the last copy +
+    # compute are not overlapped with anything, so they should be a small part of the whole (measured on 550 MB of
+    # files: 17 / 34 / 45 / 67 slabs -> 17.5 / 15.0 / 14.9 / 19.1 ms; a slab costs ~0.25 ms of host time to issue)
+    slab_bytes = max(min(slab_bytes, max(8 << 20, -(-total // 32))), 1 << 20)
+    slabs = plan_slabs(sizes, slab_bytes)
+    room = (np.maximum(sizes, 0) + 15) // 16 * 16
+    largest = max(int(room[lo:hi].sum()) for lo, hi in slabs)
+    stage = _Stage(engine, largest)
+    if stats is not None:
+        stats.update({"slabs": len(slabs), "slab_bytes": slab_bytes, "file_bytes": total, "reader_threads": host_threads(workers)})
+
+    clock = {"init_s": time.perf_counter() - t_enter, "reader_wait_pinned_s": 0.0, "reader_native_s": 0.0, "reader_fallback_s": 0.0, "main_wait_reader_s": 0.0,
+             "main_issue_s": 0.0}
+
+    def read_slab(k: int):
+        lo, hi = slabs[k]
+        t0 = time.perf_counter()
+        stage.wait_pinned_free(k)
+        t1 = time.perf_counter()
+        pin = stage.pinned(k)
+        offs = np.zeros(hi - lo, dtype=np.int64)
+        if hi - lo > 1:
+            np.cumsum(room[lo:hi - 1], out=offs[1:])
+        clips = read_wav_batch(None, pin.data_ptr(), pin.numel(), offs, room[lo:hi], table=(blob, path_at[lo:hi]),
+                               start_seconds=job_starts[lo:hi] if any_segment else None,
+                               duration_seconds=job_durations[lo:hi] if any_segment else None, threads=workers)
+        t2 = time.perf_counter()
+        # what the native reader does not take: the Python reader, here on the reader thread, so that the reference's
+        # retries (sleeps!) and host decodes run beside the GPU work, not in front of it
+        fallback = {}
+        for i in np.flatnonzero(clips["status"] != WAV_OK):
+            fallback[int(i)] = read_fallback(jobs[lo + int(i)])
+        clock["reader_wait_pinned_s"] += t1 - t0
+        clock["reader_native_s"] += t2 - t1
+        clock["reader_fallback_s"] += time.perf_counter() - t2
+        return clips, int(offs[-1] + room[hi - 1]) if hi > lo else 0, fallback
+
+    def _run_slabs():
+        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="serhip-reader") as reader:
+            ahead = deque(reader.submit(read_slab, k) for k in range(min(PINNED_BUFFERS - 1, len(slabs))))
+            for k, (lo, hi) in enumerate(slabs):
+                t0 = time.perf_counter()
+                clips, used, fallback = ahead.popleft().result()
+                t1 = time.perf_counter()
+                clock["main_wait_reader_s"] += t1 - t0
+                if k + PINNED_BUFFERS - 1 < len(slabs):
+                    ahead.append(reader.submit(read_slab, k + PINNED_BUFFERS - 1))
+                ok = clips["status"] == WAV_OK
+                raw_dev = stage.upload(k, used if ok.any() else 0)
+                # one GPU batch per (sample rate, sample format) of the slab -- normally one
+                if ok.any():
+                    keys = clips["sample_rate"].astype(np.int64) * 2 + clips["sample_format"]
+                    for key in np.unique(keys[ok]):
+                        idx = np.flatnonzero(ok & (keys == key))
+                        rate, fmt = int(key // 2), SAMPLE_FORMAT_NAMES[int(key % 2)]
+                        try:
+                            dsp.check_flags_for_rate(feature_flags, rate)
+                        except Exception as err:   # a property of the rate, not of a clip: every clip of the group, no retries
+                            for i in idx:
+                                errors[lo + int(i)] = err
+                            continue
+
+                        def run_raw(sub, rate=rate, fmt=fmt):
+                            sub = np.asarray(sub, dtype=np.int64)
+                            audio, out_off, frames = engine.prepare_audio(raw_dev, fmt, clips["raw_offset"][sub],
+                                                                          clips["frames"][sub], clips["channels"][sub])
+                            rows = lo + sub
+                            if len(rows) == int(rows[-1] - rows[0]) + 1:   # consecutive jobs: the kernels write their rows in place
+                                engine.features(audio, out_off, frames, rate, feature_flags, out=matrix[int(rows[0]):int(rows[-1]) + 1])
+                            else:
+                                matrix.index_copy_(0, torch.from_numpy(rows).to(engine.device),
+                                                   engine.features(audio, out_off, frames, rate, feature_flags))
+                        bisect(idx, run_raw, lambda i, err: errors.__setitem__(lo + int(i), err))
+                stage.computed(k)
+                # host-decoded clips and failures of this slab (rare): after the slab's GPU work has been enqueued
+                host_groups: dict[int, list[tuple[int, np.ndarray]]] = {}
+                for i, (kind, value, err) in fallback.items():
+                    if kind is None:
+                        errors[lo + i] = err
+                        continue
+                    try:
+                        dsp.validate_signal(value[0], int(value[1]))
+                        host_groups.setdefault(int(value[1]), []).append((i, value[0]))
+                    except Exception as err2:
+                        errors[lo + i] = err2
+                for rate, members in host_groups.items():
+                    run_host_group(lo, rate, members)
+                clock["main_issue_s"] += time.perf_counter() - t1
+
+    # Two Python threads take turns here (the reader thread returns from its native call about once a millisecond
+    # and must re-acquire the GIL to hand over the slab).  CPython makes a thread that wants the GIL wait up to the
+    # switch interval -- 5 ms by default, several slabs' worth -- for a running thread to yield, so for the duration
+    # of the loop the interval is lowered (process-wide, restored on the way out).
+    import sys
+
+    switch_interval = sys.getswitchinterval()
+    sys.setswitchinterval(float(os.environ.get("SERHIP_SWITCH_INTERVAL", 2e-5)))
+    try:
+        _run_slabs()
+    finally:
+        sys.setswitchinterval(switch_interval)
+    if stats is not None:
+        stats.update(clock)
+        stats["total_s"] = time.perf_counter() - t_enter
+    stage.finish()
+
+
+# ------------------------------------------------------------------------------------------ host buffer -> features
+def features_from_host(engine, audio: np.ndarray, seg_offset: np.ndarray, seg_len: np.ndarray, sample_rate: int, flags,
+                       *, out=None, chunk_bytes: int | None = None, threads: int | None = None, stats: dict | None = None):
+    """``engine.features`` for float32 audio in pageable host memory with non-decreasing segment offsets: the buffer
+    goes to the GPU chunk by chunk (parallel memcpy into pinned staging, asynchronous H2D on the copy stream) and
+    the segments of a chunk are featurised while the next chunk is staged.  Returns the ``[n_seg, D]`` device tensor."""
+    torch = engine._torch
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    off = np.ascontiguousarray(seg_offset, dtype=np.int64)
+    length = np.ascontiguousarray(seg_len, dtype=np.int64)
+    n_seg, dim = int(off.shape[0]), flags.width()
+    if out is None:
+        out = torch.empty((n_seg, dim), dtype=torch.float32, device=engine.device)
+    if n_seg == 0 or dim == 0:
+        return out
+    if (off < 0).any() or (length < 1).any() or int((off + length).max()) > audio.shape[0]:
+        raise ValueError("a segment is empty or lies outside the audio buffer")
+    chunk_bytes = chunk_bytes or _env_bytes("SERHIP_CHUNK_BYTES", DEFAULT_CHUNK_BYTES)
+    # chunks of consecutive segments: [first sample of the first, furthest end among them) must fit a staging buffer
+    ends = np.maximum.accumulate(off + length)
+    chunks, i = [], 0
+    limit = chunk_bytes // 4
+    while i < n_seg:
+        j = int(np.searchsorted(ends, off[i] + limit, side="right"))
+        j = max(j, i + 1)
+        chunks.append((i, j, int(off[i]), int(ends[j - 1])))
+        i = j
+    largest = max(b - a for _, _, a, b in chunks) * 4
+    stage = _Stage(engine, largest)
+    n_threads = host_threads(threads)
+    if stats is not None:
+        stats.update({"chunks": len(chunks), "chunk_bytes": largest, "memcpy_threads": n_threads})
+    src = audio.ctypes.data
+
+    def stage_chunk(k: int):
+        _, _, a, b = chunks[k]
+        stage.wait_pinned_free(k)
+        parallel_memcpy(stage.pinned(k).data_ptr(), src + 4 * a, 4 * (b - a), n_threads)
+
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="serhip-stager") as stager:
+        ahead = deque(stager.submit(stage_chunk, k) for k in range(min(PINNED_BUFFERS - 1, len(chunks))))
+        for k, (i0, i1, a, b) in enumerate(chunks):
+            ahead.popleft().result()
+            if k + PINNED_BUFFERS - 1 < len(chunks):
+                ahead.append(stager.submit(stage_chunk, k + PINNED_BUFFERS - 1))
+            dev = stage.upload(k, 4 * (b - a)).view(torch.float32)
+            engine.features(dev, off[i0:i1] - a, length[i0:i1], sample_rate, flags, out=out[i0:i1])
+            stage.computed(k)
+    stage.finish()
+    return out

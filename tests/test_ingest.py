@@ -1,0 +1,269 @@
+"""The overlapped ingest path (ser_amd/ingest.py + serhip_read_wav_batch / serhip_stat_files /
+serhip_parallel_memcpy): the GPU-side counterpart of the reference's ``Pool.imap_unordered`` over files
+(ser/_internal/data/data_loader.py:368-379).
+
+CPU tests: the native reader sees what the Python reader (``audio_io.read_raw_clip``) sees -- same payload bytes,
+same frame selection, same verdict on what it does not take.  GPU tests: the pipelined loader returns the
+sequential loader's bits, a failing file is reported alone, a host buffer streamed in chunks gives the whole-buffer
+result."""
+
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+def _wav_bytes(fmt_code: int, bits: int, channels: int, rate: int, payload: bytes, *, junk: bytes = b"abcd") -> bytes:
+    block = channels * bits // 8
+    fmt = struct.pack("<HHIIHH", fmt_code, channels, rate, rate * block, block, bits)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if junk is not None:
+        body += b"LIST" + struct.pack("<I", len(junk)) + junk + (b"\0" if len(junk) & 1 else b"")
+    body += b"data" + struct.pack("<I", len(payload)) + payload
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def _corpus(tmp_path, rng):
+    """[(path, start, duration)] over every kind of file the reader meets; returns jobs and the index of each kind"""
+    files = {}
+
+    def put(name, data):
+        p = tmp_path / name
+        p.write_bytes(data)
+        files[name] = str(p)
+        return str(p)
+
+    put("mono16.wav", _wav_bytes(1, 16, 1, 16000, rng.integers(-30000, 30000, 5000, dtype=np.int16).astype("<i2").tobytes()))
+    put("stereo16.wav", _wav_bytes(1, 16, 2, 8000, rng.integers(-30000, 30000, (999, 2), dtype=np.int16).astype("<i2").tobytes()))
+    put("f32.wav", _wav_bytes(3, 32, 1, 22050, rng.standard_normal(777).astype("<f4").tobytes()))
+    # a LIST chunk of 6 bytes puts the float32 payload on a 2-byte boundary: the reader slides it to a 4-byte one
+    put("f32_misaligned.wav", _wav_bytes(3, 32, 2, 22050, rng.standard_normal((300, 2)).astype("<f4").tobytes(), junk=b"abcdef"))
+    put("nolist.wav", _wav_bytes(1, 16, 1, 16000, rng.integers(-100, 100, 2500, dtype=np.int16).astype("<i2").tobytes(), junk=None))
+    put("pcm24.wav", _wav_bytes(1, 24, 1, 16000, bytes(300)))
+    put("lfs.wav", b"version https://git-lfs.github.com/spec/v1\noid sha256:0\nsize 1\n")
+    put("junk.wav", b"not audio at all")
+    put("truncated.wav", _wav_bytes(1, 16, 1, 16000, bytes(2000))[:-500])     # data chunk runs past the end of the file
+    put("empty.wav", _wav_bytes(1, 16, 1, 16000, b""))
+    files["missing.wav"] = str(tmp_path / "missing.wav")
+    (tmp_path / "dir.wav").mkdir()
+    files["dir.wav"] = str(tmp_path / "dir.wav")
+    jobs = [(files[n], None, None) for n in files]
+    jobs += [(files["stereo16.wav"], 0.05, 0.01), (files["mono16.wav"], 0.1, None), (files["mono16.wav"], None, 0.05),
+             (files["mono16.wav"], 10.0, None), (files["f32.wav"], 0.01, 0.02)]
+    return jobs
+
+
+def test_native_reader_agrees_with_the_python_reader(tmp_path, native_lib):
+    from ser_amd import ingest
+    from ser_amd.audio_io import read_raw_clip
+
+    rng = np.random.default_rng(5)
+    jobs = _corpus(tmp_path, rng)
+    paths = [j[0] for j in jobs]
+    sizes = ingest.stat_files(paths, threads=4)
+    for p, s in zip(paths, sizes):
+        assert s == (os.path.getsize(p) if os.path.isfile(p) else -1)
+    room = (np.maximum(sizes, 0) + 15) // 16 * 16
+    offs = np.concatenate(([0], np.cumsum(room)[:-1]))
+    slab = np.full(int(room.sum()) + 64, 0xEE, dtype=np.uint8)
+    for threads in (1, 5):
+        clips = ingest.read_wav_batch(paths, slab.ctypes.data, slab.nbytes, offs, room, start_seconds=[j[1] for j in jobs],
+                                      duration_seconds=[j[2] for j in jobs], threads=threads)
+        for (path, start, dur), c in zip(jobs, clips):
+            try:
+                want = read_raw_clip(path, start_seconds=start, duration_seconds=dur)
+            except Exception:
+                want = None
+            if want is None or want.frames == 0:     # the Python loader falls back to the host reader for these
+                assert c["status"] != 0, path
+                continue
+            assert c["status"] == 0, (path, c)
+            assert (ingest.SAMPLE_FORMAT_NAMES[int(c["sample_format"])], int(c["channels"]), int(c["frames"]), int(c["sample_rate"])) == \
+                (want.sample_format, want.channels, want.frames, want.sample_rate)
+            ssize = 2 if want.sample_format == "s16" else 4
+            assert c["raw_offset"] % ssize == 0
+            got = slab[int(c["raw_offset"]): int(c["raw_offset"]) + len(want.payload)]
+            assert got.tobytes() == bytes(want.payload), path
+    status = {os.path.basename(p) + (f"@{s},{d}" if (s, d) != (None, None) else ""): int(c["status"]) for (p, s, d), c in zip(jobs, clips)}
+    assert status["pcm24.wav"] == 1 and status["missing.wav"] == 2 and status["dir.wav"] == 2 and status["lfs.wav"] == 3
+    assert status["junk.wav"] == 4 and status["empty.wav"] == 6 and status["mono16.wav@10.0,None"] == 6
+    assert status["truncated.wav"] == 0
+    # a region smaller than the file: reported, nothing written past the region
+    small = np.full(64, 0xEE, dtype=np.uint8)
+    c = ingest.read_wav_batch(paths[:1], small.ctypes.data, small.nbytes, np.zeros(1, np.int64), np.array([32]), threads=1)
+    assert int(c["status"][0]) == 5 and (small == 0xEE).all()
+    # regions outside dst are a caller error
+    from ser_amd._native import SerhipError
+
+    with pytest.raises(SerhipError, match="lies outside dst"):
+        ingest.read_wav_batch(paths[:1], small.ctypes.data, small.nbytes, np.array([48]), np.array([32]), threads=1)
+
+
+def test_parallel_memcpy_and_slab_plan(native_lib):
+    from ser_amd import ingest
+
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 255, size=(9 << 20) + 13, dtype=np.uint8)
+    for threads in (1, 3, 8):
+        dst = np.zeros_like(src)
+        ingest.parallel_memcpy(dst.ctypes.data, src.ctypes.data, src.nbytes, threads)
+        assert np.array_equal(dst, src)
+    sizes = np.array([100, 100, -1, 5000, 100, 100, 100], dtype=np.int64)     # 112-byte rooms; one missing; one oversize
+    assert ingest.plan_slabs(sizes, 300) == [(0, 3), (3, 4), (4, 6), (6, 7)]
+    assert ingest.plan_slabs(sizes, 1 << 20) == [(0, 7)]
+    assert ingest.plan_slabs(np.zeros(0, np.int64), 300) == []
+    blob, offsets = ingest.encode_paths(["a", "bcd", "éf"])
+    assert blob == b"a\0bcd\0\xc3\xa9f\0" and offsets.tolist() == [0, 2, 6]
+
+
+def test_bisect_raises_device_and_config_errors_at_once():
+    """only per-clip / size-dependent failures are bisected."""
+    from ser_amd._native import SerhipError
+    from ser_amd.data_loader import _bisecting
+
+    calls = []
+
+    def run_factory(err):
+        def run(sub):
+            calls.append(list(sub))
+            raise err
+        return run
+
+    for err in (SerhipError(-2, "hipErrorIllegalAddress"), NotImplementedError("tonnetz"), RuntimeError("HIP error: an illegal memory access")):
+        calls.clear()
+        with pytest.raises(type(err)):
+            _bisecting(list(range(8)), run_factory(err), lambda i, e: None)
+        assert calls == [list(range(8))]
+    reported = []
+    calls.clear()
+
+    def run(sub):
+        calls.append(list(sub))
+        if 5 in sub:
+            raise SerhipError(-1, "segment 5 is empty")
+    _bisecting(list(range(8)), run, lambda i, e: reported.append(i))
+    assert reported == [5] and len(calls) == 7
+    calls.clear()
+    reported.clear()
+
+    def run_oom(sub):
+        calls.append(list(sub))
+        if len(sub) > 2:
+            raise RuntimeError("HIP out of memory. Tried to allocate 1 GiB")
+    _bisecting(list(range(8)), run_oom, lambda i, e: reported.append(i))
+    assert reported == [] and [len(c) for c in calls] == [8, 4, 2, 2, 4, 2, 2]
+
+
+# ------------------------------------------------------------------------------------------------------- GPU
+def _dataset(tmp_path, rng, n=40):
+    """n readable clips of three kinds (PCM16 mono 16 kHz, PCM16 stereo 16 kHz, float32 mono 22.05 kHz) and lengths
+    0.4-1.6 s, plus the unreadable ones of _corpus in between"""
+    jobs = []
+    for i in range(n):
+        kind = i % 3
+        n_samples = int(rng.integers(6400, 25600))
+        if kind == 0:
+            data = _wav_bytes(1, 16, 1, 16000, (rng.standard_normal(n_samples) * 6000).astype("<i2").tobytes())
+        elif kind == 1:
+            data = _wav_bytes(1, 16, 2, 16000, (rng.standard_normal((n_samples, 2)) * 6000).astype("<i2").tobytes())
+        else:
+            data = _wav_bytes(3, 32, 1, 22050, rng.standard_normal(n_samples).astype("<f4").tobytes())
+        p = tmp_path / f"clip{i:03d}.wav"
+        p.write_bytes(data)
+        jobs.append((str(p), None, None))
+    return jobs
+
+
+@pytest.mark.gpu
+def test_pipelined_loader_equals_sequential_and_isolates_failures(tmp_path, monkeypatch):
+    import torch
+
+    from ser_amd import AudioReadConfig, FeatureFlags
+    from ser_amd.audio_io import AudioDecodeError, AudioIntegrityError
+    from ser_amd.data_loader import featurize_audio_jobs_device
+
+    rng = np.random.default_rng(17)
+    good = _dataset(tmp_path, rng)
+    bad_dir = tmp_path / "bad"
+    bad_dir.mkdir()
+    bad = _corpus(bad_dir, rng)
+    # bad files spread over the slabs: after every fourth good one
+    jobs, k = [], 0
+    for i, job in enumerate(good):
+        jobs.append(job)
+        if i % 4 == 3 and k < len(bad):
+            jobs.append(bad[k])
+            k += 1
+    jobs += bad[k:]
+    flags = FeatureFlags(tonnetz=False)
+    cfg = AudioReadConfig(max_retries=1, retry_delay_seconds=0.0)
+    seq, seq_err = featurize_audio_jobs_device(jobs, feature_flags=flags, audio_read_config=cfg, workers=4, pipelined=False)
+    for slab_bytes in (1 << 20, 64 << 20):     # ~10 slabs (the floor of 1 MiB applies), then a single one
+        monkeypatch.setenv("SERHIP_SLAB_BYTES", str(slab_bytes))
+        stats = {}
+        pip, pip_err = featurize_audio_jobs_device(jobs, feature_flags=flags, audio_read_config=cfg, workers=4, pipelined=True,
+                                                   stats=stats)
+        torch.cuda.synchronize()
+        assert stats["slabs"] >= (2 if slab_bytes == 1 << 20 else 1)
+        a, b = seq.cpu().numpy(), pip.cpu().numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        np.testing.assert_array_equal(np.nan_to_num(a), np.nan_to_num(b))          # bit-equal rows
+        for (path, _s, _d), e_seq, e_pip, row in zip(jobs, seq_err, pip_err, b):
+            assert type(e_seq) is type(e_pip), (path, e_seq, e_pip)
+            assert (e_pip is None) == bool(np.isfinite(row).all()), path
+    names = {os.path.basename(p): e for (p, s, d), e in zip(jobs, pip_err) if (s, d) == (None, None)}
+    assert isinstance(names["missing.wav"], FileNotFoundError) and isinstance(names["lfs.wav"], AudioIntegrityError)
+    assert isinstance(names["junk.wav"], AudioDecodeError) and isinstance(names["empty.wav"], OSError)
+    assert names["pcm24.wav"] is None and names["truncated.wav"] is None     # host-decoded / cut at the end of the file
+    assert all(e is None for n, e in names.items() if n.startswith("clip"))
+    # the 8 kHz stereo file fails for the reference's reason (spectral_contrast needs sr > 12 800), alone
+    assert "stereo16.wav" in names and names["stereo16.wav"] is not None
+
+
+@pytest.mark.gpu
+def test_pipelined_loader_overlaps_and_reuses_its_buffers(tmp_path, monkeypatch):
+    """Two calls in a row on the same engine (the staging buffers are kept), the second on a smaller corpus."""
+    import torch
+
+    from ser_amd import AudioReadConfig, FeatureFlags
+    from ser_amd.data_loader import featurize_audio_jobs_device
+
+    rng = np.random.default_rng(23)
+    jobs = _dataset(tmp_path, rng, n=30)
+    flags = FeatureFlags(tonnetz=False)
+    cfg = AudioReadConfig(max_retries=1, retry_delay_seconds=0.0)
+    monkeypatch.setenv("SERHIP_SLAB_BYTES", str(1 << 20))
+    want, _ = featurize_audio_jobs_device(jobs, feature_flags=flags, audio_read_config=cfg, pipelined=False)
+    for subset in (jobs, jobs[:7], jobs):
+        got, errs = featurize_audio_jobs_device(subset, feature_flags=flags, audio_read_config=cfg, pipelined=True)
+        torch.cuda.synchronize()
+        assert all(e is None for e in errs)
+        np.testing.assert_array_equal(got.cpu().numpy(), want[: len(subset)].cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_host_buffer_streams_in_chunks_with_the_whole_buffer_result():
+    import torch
+
+    from ser_amd import FeatureFlags
+    from ser_amd.engine import get_engine
+    from ser_amd.ingest import features_from_host
+    from ser_amd.synth import harmonic_clips
+
+    eng = get_engine()
+    flags = FeatureFlags(tonnetz=False)
+    clips = harmonic_clips(np.random.default_rng(2), 24, 48000, 16000)
+    audio = np.ascontiguousarray(clips.reshape(-1))
+    # ragged, overlapping, non-decreasing segments: windows of 3 s at a 1 s stride plus whole clips
+    off = np.sort(np.concatenate([np.arange(0, audio.size - 48000, 16000), np.arange(24) * 48000])).astype(np.int64)
+    length = np.minimum(48000, audio.size - off)
+    want = eng.features(torch.from_numpy(audio).to(eng.device), off, length, 16000, flags)
+    for chunk_bytes in (1 << 20, 3 << 19, 64 << 20):
+        stats = {}
+        got = features_from_host(eng, audio, off, length, 16000, flags, chunk_bytes=chunk_bytes, stats=stats)
+        torch.cuda.synchronize()
+        assert stats["chunks"] >= (3 if chunk_bytes < (4 << 20) else 1)
+        np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+    with pytest.raises(ValueError, match="outside the audio buffer"):
+        features_from_host(eng, audio, np.array([audio.size - 10]), np.array([48000]), 16000, flags)
