@@ -11,6 +11,8 @@ n = 12500
 audio = harmonic_clips_torch(1234, n, 48000, eng.device).reshape(-1)
 offs = np.arange(n, dtype=np.int64) * 48000; lens = np.full(n, 48000)
 fl = FeatureFlags(tonnetz=False) if not os.environ.get("EXP_CHROMA_ONLY") else FeatureFlags(mfcc=False, mel=False, contrast=False, tonnetz=False)
+if os.environ.get("EXP_NO_CHROMA"):   # k_stft_frames<true, false>: no peak scan, control flow independent of the data
+    fl = FeatureFlags(chroma=False, tonnetz=False)
 for _ in range(2): eng.features(audio, offs, lens, 16000, fl)
 torch.cuda.synchronize()
 eng._ctx.profile_enable(True)
