@@ -240,7 +240,37 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    comm = {"world": world, "backend": None, "transport": None}
+    # per-rank account, so that the first multi-GPU run can be read from one line: every rank's kernel times per step
+    # (HIP events on its launch stream), its wall time per step, and the all-gather alone (blocking, timed with events
+    # after the measured loop, outside it)
+    mine_ms = {"rank": rank, "stft_ms": k1_ms / max(1, args.steps), "finish_ms": k2_ms / max(1, args.steps),
+               "project_ms": k3_ms / max(1, args.steps), "step_ms_median": step_ms[len(step_ms) // 2],
+               "wall_ms_per_step": elapsed / args.steps * 1e3, "gather_alone_ms": None}
+    if world > 1:
+        from ser_amd.distributed import all_gather_rows
+
+        feats_alone = engine.features(audio, offsets, lengths, SAMPLE_RATE, flags)
+        if args.rehearse_on_one_gpu:
+            feats_alone = feats_alone.cpu()
+        all_gather_rows(feats_alone, n_total)   # warm
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_g = time.perf_counter()
+        g0.record()
+        for _ in range(3):
+            all_gather_rows(feats_alone, n_total)
+        g1.record()
+        torch.cuda.synchronize()
+        mine_ms["gather_alone_ms"] = max(g0.elapsed_time(g1), (time.perf_counter() - t_g) * 1e3) / 3
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_ms)
+    else:
+        per_rank = [mine_ms]
+
+    comm = {"world": world, "backend": None, "transport": None, "per_rank": per_rank,
+            "gather": "one all_gather_into_tensor of [clips_per_gpu, 187] float32 per rank and step (9.35 MB per rank at "
+                      "config 3), left in flight under the next step's kernels"}
     if world > 1:
         comm["backend"] = "rccl (torch.distributed 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend()
         if nccl_log and rank == 0:
@@ -263,7 +293,7 @@ def main() -> None:
         # dominant kernel: algorithmic bytes of the rank's batch per step / its event time per step
         k1_s_per_step = (k1_ms / 1e3) / max(1, args.steps)
         achieved = n_local * ALGO_BYTES_PER_CLIP / k1_s_per_step / 1e9 if k1_s_per_step > 0 else 0.0
-        traffic = None
+        traffic = frac_rocprof = rocprof_ms = profile_tag = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
@@ -271,8 +301,13 @@ def main() -> None:
                 # PMC bytes of one profiled launch, scaled to this run's clips per launch
                 traffic = prof["k_stft_frames_hbm_bytes_per_launch"] * (
                     n_local / max(1, k1_n / max(1, args.steps)) / prof["k_stft_frames_segments_per_launch_avg"])
+                # the same fraction from the committed rocprofv3 kernel trace of this command (profiles/<tag>_kernel_stats.csv):
+                # algorithmic bytes of a profiled launch / the kernel's average duration there / peak
+                profile_tag = prof.get("tag")
+                rocprof_ms = prof.get("k_stft_frames_rocprof_avg_us") / 1e3
+                frac_rocprof = (prof["k_stft_frames_algorithmic_bytes_per_launch_avg"] / (rocprof_ms / 1e3) / 1e9) / HBM_PEAK_GBS
             except Exception:
-                traffic = None
+                pass
         line = {
             "metric": "audio-seconds featurized/sec (whole node)",
             "value": value,
@@ -306,8 +341,14 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "frac_source": "HIP events on the launch stream, this run",
+                "frac_rocprof": frac_rocprof,
+                "frac_rocprof_source": None if profile_tag is None else
+                    f"profiles/{profile_tag}_kernel_stats.csv: k_stft_frames AverageNs = {rocprof_ms:.3f} ms per 12 500-clip launch "
+                    "(rocprofv3 --kernel-trace --stats of this command, committed; kernels run 5-15 % longer under the "
+                    "profiler than by events in the same process, DESIGN.md section 5)",
                 "traffic": traffic,
-                "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this command: TCC FETCH/WRITE_SIZE, "
+                "traffic_source": f"profiles/traffic.json (tag {profile_tag}: rocprofv3 PMC passes of this command, TCC FETCH/WRITE_SIZE, "
                                   "guide's gfx950 corrections), scaled to this run's clips per launch; not re-measured live",
                 "launches_per_step": k1_n / max(1, args.steps),
                 "avg_launch_ms": k1_ms / max(1, k1_n),

@@ -39,6 +39,9 @@ HBM = 8.0e12
 FLAGS = FeatureFlags(tonnetz=False)
 
 
+INVOCATIONS = {"n": 0}   # calls of the timed closures since the last reset (profiles divide kernel totals by it)
+
+
 def timed(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -46,6 +49,7 @@ def timed(fn, reps):
     for _ in range(reps):
         out = fn()
     torch.cuda.synchronize()
+    INVOCATIONS["n"] += reps + 1
     return (time.perf_counter() - t0) / reps, out
 
 
@@ -69,6 +73,7 @@ def config1(eng, res):
     assert len(offs) == 5
     dt, out = timed(lambda: eng.features(audio, offs, lens, SR, FLAGS), 50)
     res["config1"] = {"what": "69 937-sample recording, 5 windows (3 s / 1 s), features on device", "ms": dt * 1e3,
+                      "algorithmic_bytes": 4 * int(audio.numel()) + 5 * 4 * 187,
                       "audio_seconds_per_s": (audio.numel() / SR) / dt}
 
 
@@ -82,6 +87,7 @@ def config2_scaled(eng, res):
     dt, out = timed(lambda: eng.features(clips, offs2, lens2, SR, FLAGS), 5)
     sec = n * 1.5
     res["config2_scaled"] = {"what": f"{n} clips x 1.5 s (47 frames each)", "ms": dt * 1e3, "audio_seconds_per_s": sec / dt,
+                             "algorithmic_bytes": n * (4 * 24000 + 4 * 187),
                              "hbm_roofline_frac": (sec / dt) * (4 * 24000 + 4 * 187) / 1.5 / HBM}
 
 
@@ -93,10 +99,16 @@ def config4(eng, res):
     assert len(offs4) == 3600
     dt, out = timed(lambda: eng.features(hour, offs4, lens4, SR, FLAGS), 10)
     res["config4"] = {"what": "1 h recording, 3 600 overlapping windows by descriptor (no copies)", "ms": dt * 1e3,
-                      "audio_seconds_per_s": 3600.0 / dt,
+                      "audio_seconds_per_s": 3600.0 / dt, "algorithmic_bytes": 3600 * (4 * SR + 4 * 187),
                       "hbm_roofline_frac": (3600.0 / dt) * (4 * SR + 4 * 187) / HBM}
+
+
+def config4_host_api(eng, res):
+    hour = harmonic_clips_torch(4321, 3600, SR, eng.device).reshape(-1)
+    hour = hour / hour.abs().max()
     backend = HandcraftedBackend(feature_flags=FLAGS)
     host_hour = hour.cpu().numpy()
+    del hour
     times = []
     for _ in range(3):   # the first pass pays one-time costs (pooling workspace, staging buffers, page faults of the host buffer)
         t0 = time.perf_counter()
@@ -115,7 +127,8 @@ def config5(eng, res):
     dt, out = timed(lambda: eng.whisper_logmel(clips5, n_mels=80), 10)
     sec = b * 30.0
     res["config5"] = {"what": f"{b} x 30 s clips -> [{b}, 80, 3000] log-mel", "ms": dt * 1e3,
-                      "audio_seconds_per_s": sec / dt, "hbm_roofline_frac": (sec / dt) * 96000 / HBM}
+                      "audio_seconds_per_s": sec / dt, "algorithmic_bytes": int(sec * 96000),
+                      "hbm_roofline_frac": (sec / dt) * 96000 / HBM}
 
 
 def generic_short(eng, res):
@@ -129,8 +142,52 @@ def generic_short(eng, res):
     dt, out = timed(lambda: eng.features(audio, offs, lens, SR, FLAGS), 3)
     sec = n * length / SR
     res["generic_short"] = {"what": f"{n} segments x {length} samples (n_fft = {length}: direct f64 DFT path)", "ms": dt * 1e3,
-                            "audio_seconds_per_s": sec / dt,
+                            "audio_seconds_per_s": sec / dt, "algorithmic_bytes": n * (4 * length + 4 * 187),
                             "hbm_roofline_frac": (sec / dt) * (4 * length + 4 * 187) / (length / SR) / HBM}
+
+
+def classifier(eng, res):
+    """StandardScaler + MLP(187 -> 300 -> 8) forward pass on a device-resident feature matrix (k_mlp_*): the
+    reference's model.predict / predict_proba (fast_path.py:180-192) for one GPU's shard of config 3."""
+    from ser_amd.classifier import GpuEmotionClassifier
+
+    rng = np.random.default_rng(0)
+    n = 12500
+    clf = GpuEmotionClassifier(classes=[f"e{i}" for i in range(8)], coefs=[rng.standard_normal((187, 300)) * 0.1,
+                                                                           rng.standard_normal((300, 8)) * 0.1],
+                               intercepts=[rng.standard_normal(300), rng.standard_normal(8)], mean=rng.standard_normal(187),
+                               scale=rng.uniform(0.5, 2.0, 187))
+    x = torch.from_numpy(rng.standard_normal((n, 187)).astype(np.float32)).to(eng.device)
+    dt, _ = timed(lambda: clf.predict_device(x), 10)
+    flop = 2.0 * n * (187 * 300 + 300 * 8)
+    res["classifier"] = {"what": f"{n} x 187 float32 features -> scaler + 300-unit relu MLP + softmax (float64 arithmetic)",
+                         "ms": dt * 1e3, "rows_per_s": n / dt, "f64_gflops": flop / dt / 1e9,
+                         "algorithmic_bytes": n * (187 * 4 + 8 * 8 + 4)}
+
+
+def pooling(eng, res):
+    """mean_std_pool over one hour of windows (k_pool_windows): 3 600 x 187 embeddings, 719 windows of 10 s / 5 s."""
+    emb = torch.randn((3600, 187), device=eng.device)
+    lo = np.arange(0, 3591, 5, dtype=np.int32)
+    hi = np.minimum(lo + 12, 3600).astype(np.int32)
+    dt, out = timed(lambda: eng.pool_windows(emb, lo, hi, mode=0), 50)
+    res["pooling"] = {"what": f"[3600, 187] float32 -> {len(lo)} windows x [mean | std] float64", "ms": dt * 1e3,
+                      "algorithmic_bytes": 3600 * 187 * 4 + len(lo) * 374 * 8}
+
+
+def prepare(eng, res):
+    """Device-side _prepare_audio_buffer + PCM16 conversion (k_prepare_convert / k_prepare_normalise): 12 500 stereo
+    PCM16 clips of 3 s already in HBM -> mono float32, scrubbed, peak-normalised."""
+    n, frames = 12500, 48000
+    raw = torch.randint(-20000, 20000, (n * frames * 2,), dtype=torch.int16, device=eng.device).view(torch.uint8)
+    off = np.arange(n, dtype=np.int64) * frames * 4
+    fr = np.full(n, frames, dtype=np.int64)
+    ch = np.full(n, 2, dtype=np.int32)
+    dt, _ = timed(lambda: eng.prepare_audio(raw, "s16", off, fr, ch), 5)
+    nbytes = n * frames * (4 + 4)     # 4 B of PCM16 stereo in, 4 B of float32 out per frame
+    res["prepare"] = {"what": f"{n} stereo PCM16 clips x 3 s in HBM -> mono float32 peak-normalised", "ms": dt * 1e3,
+                      "audio_seconds_per_s": n * 3.0 / dt, "algorithmic_bytes": nbytes,
+                      "hbm_roofline_frac": nbytes / dt / HBM}
 
 
 def config2_from_files(eng, res):
@@ -278,23 +335,32 @@ def config3_from_host(eng, res):
     res["config3_from_host"] = out
 
 
-CONFIGS = {"config1": config1, "config2_scaled": config2_scaled, "config4": config4, "config5": config5,
-           "generic_short": generic_short, "config2_from_files": config2_from_files, "config3_from_host": config3_from_host}
+CONFIGS = {"config1": config1, "config2_scaled": config2_scaled, "config4": config4, "config4_host_api": config4_host_api,
+           "config5": config5,
+           "generic_short": generic_short, "classifier": classifier, "pooling": pooling, "prepare": prepare,
+           "config2_from_files": config2_from_files, "config3_from_host": config3_from_host}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="", help="comma-separated subset of: " + ", ".join(CONFIGS))
+    ap.add_argument("--out", default="", help="write the JSON document here instead of stdout")
     args = ap.parse_args()
     names = [n for n in args.only.split(",") if n] or list(CONFIGS)
     eng = get_engine()
     res = {}
     for name in names:
+        INVOCATIONS["n"] = 0
         CONFIGS[name](eng, res)
+        if name in res:
+            res[name]["timed_invocations"] = INVOCATIONS["n"]
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         print(f"[bench_configs] {name} done", file=sys.stderr, flush=True)
-    print(json.dumps(res, indent=1))
+    if args.out:
+        Path(args.out).write_text(json.dumps(res, indent=1))
+    else:
+        print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":

@@ -35,15 +35,23 @@ def main():
         if on:
             keep.append(line)
     (dst / f"{tag}_summary.txt").write_text(
-        f"# rocprofv3 --kernel-trace --stats + PMC passes of `python3 bench.py --steps 3 --warmup 1 --cpu-clips 0` "
+        f"# rocprofv3 --kernel-trace --stats + PMC passes of `python3 bench.py --steps 10 --warmup 2 --cpu-clips 0` "
         f"(scripts/profile_gpu.sh {tag})\n# per-launch averages; one launch = 12 500 clips = 1 175 000 STFT frames\n"
         + "\n".join(keep) + "\n")
     bench = ROOT / "gpurun_out" / f"bench_{tag}.json"
     if bench.exists():
         shutil.copy(bench, dst / f"{tag}_bench.json")
+    in_trace = src / f"bench_in_trace_{tag}.json"
+    if in_trace.exists() and in_trace.stat().st_size:
+        shutil.copy(in_trace, dst / f"{tag}_bench_in_trace.json")
     kernels = json.load(open(dst / f"{tag}_summary.json"))["kernels"]
     k = kernels["k_stft_frames"]["pmc_avg_per_launch"]
     json.dump({
+        "tag": tag,
+        "k_stft_frames_rocprof_avg_us": kernels["k_stft_frames"]["trace"]["avg_us"],
+        "k_stft_frames_rocprof_median_us": kernels["k_stft_frames"]["trace"]["median_us"],
+        "k_stft_frames_rocprof_launches": kernels["k_stft_frames"]["trace"]["calls"],
+        "k_project_frames_rocprof_avg_us": kernels.get("k_project_frames", {}).get("trace", {}).get("avg_us"),
         "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md)",
         "k_stft_frames_hbm_bytes_per_launch": k["hbm_bytes_per_launch_corrected"],

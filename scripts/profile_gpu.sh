@@ -8,8 +8,14 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --cpu-clips 0"
+# 12 launches per kernel: the first (cold scratch pages, cold tables: +35 % on k_project_frames) weighs 1/12 in the averages
+BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --cpu-clips 0"
+# the plain run first (no profiler): the bench line with the CPU baseline
+( cd "$ROOT" && timeout -k 10 400 python3 bench.py > "$ROOT/gpurun_out/bench_$TAG.json" 2> "$ROOT/gpurun_out/bench_$TAG.err" ) || { echo "bench failed"; tail -5 "$ROOT/gpurun_out/bench_$TAG.err"; exit 1; }
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
+# the bench line printed INSIDE the traced run: HIP-event kernel times under the profiler, to set beside the
+# profiler's own durations of the same launches (is the difference the clock of the two methods, or the kernels?)
+grep -a '^{"metric"' "$OUT/trace.log" > "$OUT/bench_in_trace_$TAG.json" || true
 echo "trace done"
 i=0
 for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do

@@ -112,9 +112,9 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     // mags_group_offset(G) and lane (frame i, kk) takes float4 i*8 + kk from there: an even group and the
     // odd one after it are the two halves of the same sixteen 128-byte lines (see mags_tile_index).  Frame
     // slots past the segment's end inside a tile were never written: their rows of C are garbage and are
-    // not stored.  A tile that lies wholly past the end is replaced by the first; a wave without a
-    // tile reads the workgroup's first tile and discards it.  Every wave issues the same loads per
-    // group, unconditionally: the waits in the loop are then exact vmcnt(n) counts and the prefetch holds.
+    // not stored.  A wave loads only the tiles that hold frames (`live` below): the loop is instantiated per tile
+    // count, so inside one instantiation every step issues the same loads and the compiler's waits stay exact
+    // vmcnt(n) counts; a wave without a tile only fetches its share of the B rows and joins the barriers.
     const size_t f0 = static_cast<size_t>(sd.stft_base) + (active ? t0 : blockIdx.x * kProjWaves * kProjTile);
     const float4* ap[kProjHalves];
     ap[0] = reinterpret_cast<const float4*>(sc.mags) + (f0 >> 4) * kTileF4 + i * 8 + kk;
@@ -209,52 +209,42 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     };
     auto prog_at = [&](int G) { return prog.g[G]; };   // scalar loads (G is wave-uniform)
     // MFMAs of one group; its B rows sit in stage (G / 2) & 1, slot G & 1
-    auto compute = [&](int G, const float4 (&a)[kProjHalves], const int4& p) {
-        if (!active) return;
+    // `live` (a compile-time tag) = the number of this wave's tiles that hold frames of the segment: a wave loads and
+    // multiplies only those.  (The first form had every wave issue the loads of all kProjHalves tiles, a missing tile
+    // replaced by the first one: with 47-frame clips half of a workgroup's magnitude requests were such duplicates,
+    // and the request path is what bounds this kernel.)
+    auto compute = [&](auto live, int G, const float4 (&a)[kProjHalves], const int4& p) {
+        constexpr int kLive = decltype(live)::value;
+        if constexpr (kLive == 0) return;
         const float4* sb = &s_b[(G >> 1) & 1][G & 1][0][lane];
         if (want_chroma) {
             const float4 bc = sb[0];
 #pragma unroll
-            for (int h = 0; h < kProjHalves; ++h) c[h] = mfma4(a[h], bc, c[h]);
+            for (int h = 0; h < kLive; ++h) c[h] = mfma4(a[h], bc, c[h]);
         }
         if (want_mel) {
             float4 pw[kProjHalves];   // |X|^2 of the rounded |X|
 #pragma unroll
-            for (int h = 0; h < kProjHalves; ++h) pw[h] = float4{a[h].x * a[h].x, a[h].y * a[h].y, a[h].z * a[h].z, a[h].w * a[h].w};
+            for (int h = 0; h < kLive; ++h) pw[h] = float4{a[h].x * a[h].x, a[h].y * a[h].y, a[h].z * a[h].z, a[h].w * a[h].w};
             if (p.z & 1) {   // wave-uniform
                 const float4 bl = sb[64];
 #pragma unroll
-                for (int h = 0; h < kProjHalves; ++h) lo[h] = mfma4(pw[h], bl, lo[h]);
+                for (int h = 0; h < kLive; ++h) lo[h] = mfma4(pw[h], bl, lo[h]);
             }
             if (p.z & 2) {
                 const float4 bh = sb[128];
 #pragma unroll
-                for (int h = 0; h < kProjHalves; ++h) hi[h] = mfma4(pw[h], bh, hi[h]);
+                for (int h = 0; h < kLive; ++h) hi[h] = mfma4(pw[h], bh, hi[h]);
             }
             for (int n = p.w; n > 0; --n) retire();
         }
     };
-    auto load_a = [&](float4 (&dst)[kProjHalves], int G) {
+    auto load_a = [&](auto live, float4 (&dst)[kProjHalves], int G) {
 #pragma unroll
-        for (int h = 0; h < kProjHalves; ++h) dst[h] = load_mags(ap[h] + mags_group_offset(G));
+        for (int h = 0; h < decltype(live)::value; ++h) dst[h] = load_mags(ap[h] + mags_group_offset(G));
     };
 
     // Software pipeline over register sets, no register copies: E for even groups, O and P alternately for odd groups.
-    float4 aE[kProjHalves], aO[kProjHalves], aP[kProjHalves];
-    load_a(aE, 0);
-    load_a(aO, 1);
-#pragma unroll
-    for (int h = 0; h < kProjHalves; ++h) aP[h] = zero4;
-    float4 bE[kProjBLoads], bO[kProjBLoads];
-#pragma unroll
-    for (int j = 0; j < kProjBLoads; ++j) {
-        bE[j] = fetch_b(0, prog_at(0), j);
-        bO[j] = fetch_b(1, prog_at(1), j);
-    }
-    park_b(s_b[0][0], bE);
-    park_b(s_b[0][1], bO);
-    __syncthreads();
-
     // One step = the even group G and the odd group G + 1, whose B rows sit in stage (G / 2) & 1.  The step requests
     // the B rows of the next pair first, multiplies group G, requests the A rows of BOTH groups G + 2 and G + 3 (the
     // two halves of the same 128-byte lines: requested back to back the second load finds the lines the first one
@@ -262,36 +252,59 @@ __global__ __launch_bounds__(kProjWaves * 64) void k_project_frames(const SegDes
     // a step ago (`ao`; the even step refills `an`, the other odd set), and only then parks the new B rows in the
     // other stage -- their loads have had two groups of MFMAs to land -- behind ONE barrier per pair (per group in
     // the first form: +1.6 %; per four groups: equal): everybody finished reading that stage before the previous
-    // step's barrier.
-    auto pair_step = [&](int G, const float4 (&ao)[kProjHalves], float4 (&an)[kProjHalves]) {
-        const int G3 = min(G + 3, kGroups - 1);         // the last step fetches a B row nobody uses
+    // step's barrier.  Every wave of the workgroup runs the same number of steps and barriers whatever its `live`.
+    auto run = [&](auto live) {
+        float4 aE[kProjHalves], aO[kProjHalves], aP[kProjHalves];
+#pragma unroll
+        for (int h = 0; h < kProjHalves; ++h) aE[h] = aO[h] = aP[h] = zero4;
+        load_a(live, aE, 0);
+        load_a(live, aO, 1);
+        float4 bE[kProjBLoads], bO[kProjBLoads];
 #pragma unroll
         for (int j = 0; j < kProjBLoads; ++j) {
-            bE[j] = fetch_b(G + 2, prog_at(G + 2), j);  // G + 2 <= 64
-            bO[j] = fetch_b(G3, prog_at(G3), j);
+            bE[j] = fetch_b(0, prog_at(0), j);
+            bO[j] = fetch_b(1, prog_at(1), j);
         }
-        compute(G, aE, prog_at(G));
-        load_a(aE, G + 2);
-        load_a(an, G + 3);                              // G + 3 = 65 at the end: the unused half of the last block
-        compute(G + 1, ao, prog_at(G + 1));
-        const int next = ((G >> 1) + 1) & 1;
-        park_b(s_b[next][0], bE);
-        park_b(s_b[next][1], bO);
+        park_b(s_b[0][0], bE);
+        park_b(s_b[0][1], bO);
         __syncthreads();
-    };
-    static_assert((kGroups - 1) % 4 == 0, "the loop below takes four groups per trip");
-#pragma unroll 1
-    for (int G = 0; G < kGroups - 1; G += 4) {
-        pair_step(G, aO, aP);
-        pair_step(G + 2, aP, aO);
-    }
-    // group 64 (kGroups is odd) holds only bin 1024 and three zero pads, in the kk = 0 chunk; the other
-    // chunks of that group were never written
-    if (kk != 0) {
+        auto pair_step = [&](int G, const float4 (&ao)[kProjHalves], float4 (&an)[kProjHalves]) {
+            const int G3 = min(G + 3, kGroups - 1);         // the last step fetches a B row nobody uses
 #pragma unroll
-        for (int h = 0; h < kProjHalves; ++h) aE[h] = zero4;
-    }
-    compute(kGroups - 1, aE, prog_at(kGroups - 1));
+            for (int j = 0; j < kProjBLoads; ++j) {
+                bE[j] = fetch_b(G + 2, prog_at(G + 2), j);  // G + 2 <= 64
+                bO[j] = fetch_b(G3, prog_at(G3), j);
+            }
+            compute(live, G, aE, prog_at(G));
+            load_a(live, aE, G + 2);
+            load_a(live, an, G + 3);                        // G + 3 = 65 at the end: the unused half of the last block
+            compute(live, G + 1, ao, prog_at(G + 1));
+            const int next = ((G >> 1) + 1) & 1;
+            park_b(s_b[next][0], bE);
+            park_b(s_b[next][1], bO);
+            __syncthreads();
+        };
+        static_assert((kGroups - 1) % 4 == 0, "the loop below takes four groups per trip");
+#pragma unroll 1
+        for (int G = 0; G < kGroups - 1; G += 4) {
+            pair_step(G, aO, aP);
+            pair_step(G + 2, aP, aO);
+        }
+        // group 64 (kGroups is odd) holds only bin 1024 and three zero pads, in the kk = 0 chunk; the other
+        // chunks of that group were never written
+        if (kk != 0) {
+#pragma unroll
+            for (int h = 0; h < kProjHalves; ++h) aE[h] = zero4;
+        }
+        compute(live, kGroups - 1, aE, prog_at(kGroups - 1));
+    };
+    // tiles of this wave that hold frames (wave-uniform): 0 for a wave past the segment's end
+    const int live_tiles = active ? min(kProjHalves, (sd.n_stft - t0 + 15) >> 4) : 0;
+    static_assert(kProjHalves <= 3, "the dispatch below lists the tile counts");
+    if (live_tiles >= kProjHalves) run(std::integral_constant<int, kProjHalves>{});
+    else if (live_tiles == 0) run(std::integral_constant<int, 0>{});
+    else if (live_tiles == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, (kProjHalves > 2 ? 2 : 1)>{});
     if (active && want_mel)
         while (cur < 8) retire();
     if (!active) return;
