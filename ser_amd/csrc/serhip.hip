@@ -1327,6 +1327,16 @@ int serhip_prepare_audio(serhip_ctx* ctx, const void* raw_dev, int64_t raw_bytes
     HIP_TRY(hipEventRecord(ctx->staging_done, stream));
     HIP_TRY(hipMemsetAsync(d_peak, 0, clips.size() * sizeof(unsigned), stream));
     const unsigned char* raw = static_cast<const unsigned char*>(raw_dev);
+    if (max_frames <= kPrepFusedMaxFrames && n_clips <= 0x7fffffffLL) {
+        // clips short enough for one workgroup each: peak and normalisation in one launch, raw bytes re-read from L2
+        const dim3 grid(static_cast<unsigned>(n_clips));
+        if (sample_format == SERHIP_SAMPLE_S16)
+            hipLaunchKernelGGL(k_prepare_clip<0>, grid, dim3(256), 0, stream, raw, d_clips, out_dev);
+        else
+            hipLaunchKernelGGL(k_prepare_clip<1>, grid, dim3(256), 0, stream, raw, d_clips, out_dev);
+        HIP_TRY(hipGetLastError());
+        return SERHIP_OK;
+    }
     // enough workgroups per clip for ~4 frames per thread, bounded so that many short clips still
     // launch one modest grid
     const unsigned gx = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((max_frames + 1023) / 1024, 1024)));

@@ -146,6 +146,23 @@ def test_prepare_audio_bit_exact_vs_numpy():
         np.testing.assert_array_equal(got[o : o + n], want)
         assert np.abs(got[o : o + n]).max() == 1.0
     assert got[out_off[1] + 5] == 0.0 and got[out_off[3] + 7] == 0.0 and got[out_off[3] + 9] == 0.0
+    # --- both kernels' routes: clips of <= 2^18 frames take the fused one-workgroup-per-clip kernel (vector loads when
+    # the clip starts on a 4-byte boundary, scalar ones at offsets = 2 mod 4); a batch holding a longer clip takes the
+    # convert + normalise pair for every clip of the call
+    for long_frames in (0, 300_000):
+        pcm = [rng.integers(-32768, 32767, size=(n, c), dtype=np.int16) for n, c in ((4001, 1), (3003, 2), (1502, 1), (77, 2))]
+        if long_frames:
+            pcm.append(rng.integers(-32768, 32767, size=(long_frames, 1), dtype=np.int16))
+        blob, offs = b"", []
+        for k, c in enumerate(pcm):
+            blob += bytes((-len(blob)) % 4) + (b"\0\0" if k % 2 else b"")    # every other clip at an offset = 2 mod 4
+            offs.append(len(blob))
+            blob += c.astype("<i2").tobytes()
+        audio, out_off, frames = eng.prepare_audio(blob, "s16", offs, [c.shape[0] for c in pcm], [c.shape[1] for c in pcm])
+        got = audio.cpu().numpy()
+        for c, o, n in zip(pcm, out_off, frames):
+            raw = c.astype(np.float32) / np.float32(32768.0)
+            np.testing.assert_array_equal(got[o : o + n], ofp.read_audio_prepared(raw if c.shape[1] > 1 else raw[:, 0]))
     # --- argument errors come back as SerhipError, nothing is launched
     from ser_amd._native import SerhipError
 
