@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256) void k_dft_frames(const float* __restrict__ au
                                                     const SegDesc* __restrict__ segs, PlanTables tb,
                                                     Scratch sc) {
     __shared__ double s_x[2048];
-    __shared__ double2 s_tw[2048];
     __shared__ float s_mag[1028];
     __shared__ float s_red[4];
     __shared__ int s_cnt;
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(256) void k_dft_frames(const float* __restrict__ au
     const long long fs = static_cast<long long>(t) * hop - n / 2;
     const float* seg_audio = audio + sd.offset;
 
-    // window (scipy get_window('hann', n, fftbins=True), float64) x frame, and the twiddles
+    // window (scipy get_window('hann', n, fftbins=True), float64) x frame
     const double wstep = (kPi - (-kPi)) / static_cast<double>(n);
     for (int j = tid; j < n; j += 256) {
         const double fac = static_cast<double>(j) * wstep + (-kPi);
@@ -94,30 +93,61 @@ __global__ __launch_bounds__(256) void k_dft_frames(const float* __restrict__ au
         const long long s = fs + j;
         const float xv = (s >= 0 && s < sd.len) ? seg_audio[s] : 0.0f;
         s_x[j] = w * static_cast<double>(xv);
-        double sn, cs;
-        sincospi(2.0 * static_cast<double>(j) / static_cast<double>(n), &sn, &cs);
-        s_tw[j] = make_double2(cs, -sn);
     }
     if (tid == 0) s_cnt = 0;
     __syncthreads();
 
+    // X[k] = sum_j x_j z^j, z = exp(-i theta), theta = 2 pi k / n, by the Goertzel / Clenshaw recurrence
+    //   b_j = x_j + 2 cos(theta) b_{j+1} - b_{j+2}   (j = n-1 .. 0),   X[k] = b_0 - b_1 conj(z)
+    // in double: two arithmetic instructions per sample and bin and one broadcast LDS read per sample, where the
+    // direct sum it replaces (a 32 KB twiddle table in LDS, read at a different address by every lane) took two
+    // conflicting LDS reads per sample and bin and was bound by them: 63 -> 11 ms per 70 000 segments of 700 samples.
+    // Rounding errors grow like n^2 eps ~ 5e-10 of the frame's scale at worst (theta -> 0), a hundredth of the
+    // float32 rounding the reference applies to its double FFT (complex64) -- and four orders below the float32 FFT
+    // of the fast path.  A thread owns up to four bins (tid + 256 c): independent chains that hide the latency
+    // of the double-precision pipeline.
     float cmax = 0.0f;
-    for (int k = tid; k < nbins; k += 256) {
-        double re = 0.0, im = 0.0;
-        int idx = 0;
-        for (int j = 0; j < n; ++j) {
-            const double xv = s_x[j];
-            const double2 w = s_tw[idx];
-            re = fma(xv, w.x, re);
-            im = fma(xv, w.y, im);
-            idx += k;
-            if (idx >= n) idx -= n;
+    {
+        double c2[4], b1[4] = {0.0, 0.0, 0.0, 0.0}, b2[4] = {0.0, 0.0, 0.0, 0.0}, cs[4], sn[4];
+        const int chains = (nbins - tid + 255) / 256;   // bins tid, tid + 256, ... below nbins (<= 4: nbins <= 1024)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = tid + 256 * c;
+            sincospi(2.0 * static_cast<double>(k) / static_cast<double>(n), &sn[c], &cs[c]);
+            c2[c] = 2.0 * cs[c];
         }
-        const float re32 = static_cast<float>(re), im32 = static_cast<float>(im);  // complex64 STFT
-        const double m2 = static_cast<double>(re32) * re32 + static_cast<double>(im32) * im32;
-        const float mag = static_cast<float>(sqrt(m2));
-        s_mag[k] = mag;
-        cmax = fmaxf(cmax, mag);
+        auto sweep = [&](auto nchains) {
+            constexpr int kC = decltype(nchains)::value;
+            for (int j = n - 1; j >= 1; --j) {   // leaves b1 = b_1, b2 = b_2
+                const double xv = s_x[j];
+#pragma unroll
+                for (int c = 0; c < kC; ++c) {
+                    const double b0 = fma(c2[c], b1[c], xv) - b2[c];
+                    b2[c] = b1[c];
+                    b1[c] = b0;
+                }
+            }
+        };
+        const int wave_chains = __builtin_amdgcn_readfirstlane((nbins - (tid & ~63) + 255) / 256);   // the wave's first lane has the most
+        if (wave_chains >= 4) sweep(std::integral_constant<int, 4>{});
+        else if (wave_chains == 3) sweep(std::integral_constant<int, 3>{});
+        else if (wave_chains == 2) sweep(std::integral_constant<int, 2>{});
+        else if (wave_chains == 1) sweep(std::integral_constant<int, 1>{});
+        const double x0 = s_x[0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < chains) {
+                const int k = tid + 256 * c;
+                const double b0 = fma(c2[c], b1[c], x0) - b2[c];
+                const double re = fma(-b1[c], cs[c], b0);     // b_0 - b_1 cos(theta)
+                const double im = -(b1[c] * sn[c]);           //     - i b_1 sin(theta)
+                const float re32 = static_cast<float>(re), im32 = static_cast<float>(im);  // complex64 STFT
+                const double m2 = static_cast<double>(re32) * re32 + static_cast<double>(im32) * im32;
+                const float mag = static_cast<float>(sqrt(m2));
+                s_mag[k] = mag;
+                cmax = fmaxf(cmax, mag);
+            }
+        }
     }
     cmax = wave_max(cmax);
     if (lane == 0) s_red[wave] = cmax;
@@ -129,7 +159,12 @@ __global__ __launch_bounds__(256) void k_dft_frames(const float* __restrict__ au
             const double d = 1.0 / static_cast<double>(tb.sample_rate);
             const double val = 1.0 / (static_cast<double>(n) * d);
             float acc = 0.0f;
-            for (int k = 0; k < nbins; ++k) {
+            // the triangle of filter `tid` is zero outside (mel_f[tid], mel_f[tid + 2]): walk only the bins around
+            // it (one spare bin on each side; the weights are still evaluated exactly and zeros skipped as before,
+            // so the sum runs over the same terms in the same order as the full walk, which cost 40x the DFT)
+            const int k_lo = max(0, static_cast<int>(floor(tb.mel_f[tid] / val)) - 1);
+            const int k_hi = min(nbins - 1, static_cast<int>(ceil(tb.mel_f[tid + 2] / val)) + 1);
+            for (int k = k_lo; k <= k_hi; ++k) {
                 const float w = mel_weight_dev(tb.mel_f, tid, static_cast<double>(k) * val);
                 if (w != 0.0f) {
                     const float m = s_mag[k];
