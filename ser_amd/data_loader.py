@@ -513,13 +513,16 @@ def load_data(test_size: float | None = None, *, settings=None) -> DataSplit | N
         elif label is not None:
             wanted.append((file, label))
     matrix, failures = featurize_files([f for f, _ in wanted], settings=active)
-    rows, labels = [], []
-    for (file, label), row, failure in zip(wanted, matrix, failures):
-        if failure is not None:
-            errors.append(f"Failed to process file {file}: {failure}")
-        else:
-            rows.append(row)
-            labels.append(label)
+    failed = [i for i, failure in enumerate(failures) if failure is not None]
+    for i in failed:
+        errors.append(f"Failed to process file {wanted[i][0]}: {failures[i]}")
+    if failed:   # rows are selected with one mask, not one Python object per file
+        keep = np.ones(len(wanted), dtype=bool)
+        keep[failed] = False
+        rows = matrix[keep]
+        labels = [label for (_, label), ok in zip(wanted, keep.tolist()) if ok]
+    else:
+        rows, labels = matrix, [label for _, label in wanted]
     if errors:
         logger.warning("Skipped %s/%s files during feature extraction.", len(errors), len(files))
         for error in errors[:5]:
@@ -534,7 +537,7 @@ def load_data(test_size: float | None = None, *, settings=None) -> DataSplit | N
             "You can relax this limit by increasing the SER_MAX_FAILED_FILE_RATIO "
             "environment variable."
         )
-    if not rows:
+    if len(rows) == 0:
         logger.warning("No data found or processed.")
         return None
     if len(set(labels)) < 2:

@@ -169,7 +169,9 @@ class IngestBuffers:
 
     def ensure(self, nbytes: int) -> None:
         torch = self.torch
-        nbytes = (int(nbytes) + 4095) // 4096 * 4096
+        nbytes = max(4096, (int(nbytes) + 4095) // 4096 * 4096)   # never empty: the native reader wants a real address
+        # a previous call that ended in an exception may have left copies out of the pinned buffers in flight
+        self.copy_stream.synchronize()
         if self.pinned and self.pinned[0].numel() >= nbytes:
             return
         if self.last_use is not None:
@@ -258,8 +260,11 @@ def featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers:
     n = len(jobs)
     paths, job_starts, job_durations = (list(column) for column in zip(*jobs))   # one C-level pass over 100k tuples
     any_segment = job_starts.count(None) != n or job_durations.count(None) != n
+    t_a = time.perf_counter()
     blob, path_at = encode_paths(paths)
+    t_b = time.perf_counter()
     sizes = stat_files(None, workers, table=(blob, path_at))
+    t_c = time.perf_counter()
     total = int(np.maximum(sizes, 0).sum())
     slab_bytes = _env_bytes("SERHIP_SLAB_BYTES", DEFAULT_SLAB_BYTES)
     # ~32 slabs when the corpus is large enough to make pipelining worth it: the first read and the last copy +
@@ -273,7 +278,8 @@ def featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers:
     if stats is not None:
         stats.update({"slabs": len(slabs), "slab_bytes": slab_bytes, "file_bytes": total, "reader_threads": host_threads(workers)})
 
-    clock = {"init_s": time.perf_counter() - t_enter, "reader_wait_pinned_s": 0.0, "reader_native_s": 0.0, "reader_fallback_s": 0.0, "main_wait_reader_s": 0.0,
+    clock = {"init_s": time.perf_counter() - t_enter, "init_columns_s": t_a - t_enter, "init_encode_paths_s": t_b - t_a,
+             "init_stat_s": t_c - t_b, "init_buffers_s": time.perf_counter() - t_c, "reader_wait_pinned_s": 0.0, "reader_native_s": 0.0, "reader_fallback_s": 0.0, "main_wait_reader_s": 0.0,
              "main_issue_s": 0.0}
 
     def read_slab(k: int):

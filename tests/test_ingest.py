@@ -243,6 +243,21 @@ def test_pipelined_loader_overlaps_and_reuses_its_buffers(tmp_path, monkeypatch)
 
 
 @pytest.mark.gpu
+def test_pipelined_loader_with_nothing_readable(tmp_path):
+    """Every file missing: per-file FileNotFoundError, NaN rows, no exception from the slab machinery (a slab of zero bytes)."""
+    import torch
+
+    from ser_amd import AudioReadConfig, FeatureFlags
+    from ser_amd.data_loader import featurize_audio_jobs_device
+
+    jobs = [(str(tmp_path / f"nope{i}.wav"), None, None) for i in range(5)]
+    m, errs = featurize_audio_jobs_device(jobs, feature_flags=FeatureFlags(tonnetz=False),
+                                          audio_read_config=AudioReadConfig(max_retries=1, retry_delay_seconds=0.0), pipelined=True)
+    torch.cuda.synchronize()
+    assert all(isinstance(e, FileNotFoundError) for e in errs) and bool(torch.isnan(m).all()) and tuple(m.shape) == (5, 187)
+
+
+@pytest.mark.gpu
 def test_host_buffer_streams_in_chunks_with_the_whole_buffer_result():
     import torch
 
