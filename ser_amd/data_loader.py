@@ -164,6 +164,51 @@ def _resolve_worker_count(max_cores: int, max_workers: int, file_count: int) -> 
     return max(1, min(max_cores, max_workers, file_count))
 
 
+def sorted_glob(pattern: str) -> list[str]:
+    """``sorted(glob.glob(pattern))`` (data_loader.py:356) without glob's per-file ``os.path.join`` and generator
+    hops, which cost more than featurising the files does once the features come from a GPU (46 080 files: 0.15 s of
+    a 0.25 s ``load_data``).  Same names, same order; patterns this shortcut does not cover (``**``, no wildcard in
+    the last component, bytes) go to ``glob.glob`` itself."""
+    import fnmatch
+
+    head, tail = os.path.split(pattern)
+    if not isinstance(pattern, str) or "**" in pattern or not head or not glob.has_magic(tail):
+        return sorted(glob.glob(pattern))
+    parents = sorted(glob.glob(head)) if glob.has_magic(head) else [head]
+    hidden_ok = tail.startswith(".")
+    found: list[str] = []
+    for parent in parents:
+        try:
+            names = os.listdir(parent)
+        except OSError:       # not a directory, unreadable: glob yields nothing for it either
+            continue
+        if not hidden_ok:
+            names = [n for n in names if not n.startswith(".")]
+        prefix = parent if parent.endswith(os.sep) else parent + os.sep
+        found.extend([prefix + n for n in fnmatch.filter(names, tail)])
+    found.sort()
+    return found
+
+
+def labels_for_files(files: Sequence[str], observed_emotions: Collection[str], emotion_map: Mapping[str, str]):
+    """:func:`label_for_file` over a whole listing: ``(wanted [(file, label)], errors [str])`` in file order, one
+    tight loop (no per-file function calls: 46 080 names in 15 ms instead of 110 ms)."""
+    accepted = {code: emotion for code, emotion in emotion_map.items() if emotion and emotion in observed_emotions}
+    wanted: list[tuple[str, str]] = []
+    errors: list[str] = []
+    sep = os.sep
+    for file in files:
+        name = file[file.rfind(sep) + 1:]
+        parts = name.split("-", 3)
+        if len(parts) < 3:
+            errors.append(f"Skipping file with unexpected name format (missing emotion code): {name}")
+            continue
+        label = accepted.get(parts[2])
+        if label is not None:
+            wanted.append((file, label))
+    return wanted, errors
+
+
 def label_for_file(file: str, observed_emotions: Collection[str], emotion_map: Mapping[str, str]):
     """``(label, error)``: label None + error None means "not a target emotion" (silently skipped)."""
     file_name = os.path.basename(file)
@@ -431,9 +476,9 @@ def featurize_audio_jobs(jobs: Sequence[tuple[str, float | None, float | None]],
                                                  audio_read_config=audio_read_config, workers=workers,
                                                  device_prepare=device_prepare)
     # widened on the device (exact), so that the host sees the API's float64 without a pass of its own
-    import torch
+    from .engine import get_engine
 
-    return matrix.to(torch.float64).cpu().numpy(), errors
+    return get_engine(matrix.device.index).to_host_float64(matrix), errors
 
 
 def featurize_files(files: Sequence[str], *, settings=None, distributed: bool = False, featurize_jobs=None):
@@ -454,10 +499,12 @@ def featurize_files(files: Sequence[str], *, settings=None, distributed: bool = 
         workers = _resolve_worker_count(active.num_cores, active.max_workers, len(files))
         matrix, errors = run([(f, None, None) for f in files], feature_flags=active.feature_flags,
                              audio_read_config=active.audio_read, workers=workers)
-        if hasattr(matrix, "cpu"):
-            import torch
+        if hasattr(matrix, "is_cuda") and matrix.is_cuda:
+            from .engine import get_engine
 
-            matrix = matrix.to(torch.float64).cpu().numpy()   # widened on the device: exact, and no host pass
+            matrix = get_engine(matrix.device.index).to_host_float64(matrix)   # widened on the device: exact, no host pass
+        elif hasattr(matrix, "cpu"):
+            matrix = matrix.cpu().numpy()
         return np.asarray(matrix, dtype=np.float64), errors
     import torch
     import torch.distributed as dist
@@ -478,7 +525,13 @@ def featurize_files(files: Sequence[str], *, settings=None, distributed: bool = 
             local = local.cuda()
     else:
         local = local.cpu()   # gloo (CPU tests, rehearsals)
-    full = all_gather_rows(local, len(files)).cpu().numpy().astype(np.float64)
+    full = all_gather_rows(local, len(files))
+    if full.is_cuda:
+        from .engine import get_engine
+
+        full = get_engine(full.device.index).to_host_float64(full)
+    else:
+        full = full.numpy().astype(np.float64)
     errors: list[Exception | None] = [None] * len(files)
     owner = np.searchsorted(bounds, np.arange(len(files)), side="right") - 1
     for i in np.flatnonzero(np.isnan(full).any(axis=1)):
@@ -499,19 +552,12 @@ def load_data(test_size: float | None = None, *, settings=None) -> DataSplit | N
     resolved_test_size = active.test_size if test_size is None else test_size
     if not 0.0 < resolved_test_size < 1.0:
         raise ValueError("test_size must be between 0 and 1.")
-    files = sorted(glob.glob(active.glob_pattern))
+    files = sorted_glob(active.glob_pattern)
     if not files:
         logger.warning("No dataset files found for pattern: %s", active.glob_pattern)
         return None
 
-    errors: list[str] = []
-    wanted: list[tuple[str, str]] = []
-    for file in files:
-        label, error = label_for_file(file, observed, active.emotions)
-        if error is not None:
-            errors.append(error)
-        elif label is not None:
-            wanted.append((file, label))
+    wanted, errors = labels_for_files(files, observed, active.emotions)
     matrix, failures = featurize_files([f for f, _ in wanted], settings=active)
     failed = [i for i, failure in enumerate(failures) if failure is not None]
     for i in failed:

@@ -81,6 +81,50 @@ class FeatureEngine:
     def _stream(self) -> c_void_p:
         return c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
+    #: device matrices at least this large come back through pinned staging (below)
+    STAGED_TO_HOST_BYTES = 8 << 20
+    STAGED_CHUNK_BYTES = 8 << 20
+
+    def to_host_float64(self, matrix) -> np.ndarray:
+        """``[n, D]`` device tensor -> a freshly allocated float64 numpy array (the dtype of the reference's API,
+        SURVEY 8b).  The widening runs on the device (exact).  A large matrix is not handed to a pageable
+        ``.cpu()`` (the driver stages that through small bounce buffers: 69 MB took 16.6 ms, a fifth of a
+        46 080-file ingest): it is copied chunk by chunk into the ingest ring's pinned buffers and moved from there
+        into the numpy array by the memcpy team while the next chunk is in flight."""
+        torch = self._torch
+        wide = matrix.to(device=self.device, dtype=torch.float64).contiguous()
+        nbytes = wide.numel() * 8
+        if nbytes < self.STAGED_TO_HOST_BYTES:
+            return wide.cpu().numpy()
+        from .ingest import PINNED_BUFFERS, ingest_buffers, parallel_memcpy
+
+        out = np.empty(tuple(wide.shape), dtype=np.float64)
+        buffers = ingest_buffers(self)
+        buffers.ensure(min(nbytes, self.STAGED_CHUNK_BYTES))
+        pinned = buffers.pinned
+        chunk = min(self.STAGED_CHUNK_BYTES, *(int(p.numel()) for p in pinned))
+        flat = wide.view(torch.uint8).reshape(-1)
+        n_chunks = -(-nbytes // chunk)
+        stream = torch.cuda.current_stream(self.device)
+        events: dict[int, object] = {}
+
+        def issue(k: int) -> None:
+            lo, hi = k * chunk, min(nbytes, (k + 1) * chunk)
+            pinned[k % PINNED_BUFFERS][: hi - lo].copy_(flat[lo:hi], non_blocking=True)
+            events[k] = torch.cuda.Event()
+            events[k].record(stream)
+
+        with torch.cuda.device(self.device):
+            for k in range(min(PINNED_BUFFERS, n_chunks)):
+                issue(k)
+            for k in range(n_chunks):
+                events.pop(k).synchronize()
+                lo, hi = k * chunk, min(nbytes, (k + 1) * chunk)
+                parallel_memcpy(out.ctypes.data + lo, pinned[k % PINNED_BUFFERS].data_ptr(), hi - lo)
+                if k + PINNED_BUFFERS < n_chunks:
+                    issue(k + PINNED_BUFFERS)   # into the buffer that has just been drained
+        return out
+
     # ------------------------------------------------------------------ hot path
     def features_into(self, audio_dev, seg_offset, seg_len, sample_rate: int, flags: FeatureFlags, out, *,
                       tuning=None, plan=None):

@@ -361,3 +361,38 @@ def test_config2_training_featurisation_from_files(tmp_path):
     back = read_prepared_feature_payload(p, feature_shape=(32, 187))
     np.testing.assert_array_equal(back.x_train, x_train)
     assert back.y_test == y_test
+
+
+def test_sorted_glob_and_label_pass_equal_the_per_file_forms(tmp_path):
+    """``sorted_glob`` / ``labels_for_files`` are the loop-free forms of ``sorted(glob.glob(...))`` and
+    ``label_for_file`` (reference: data_loader.py:356-366, 234-262): same files, same order, same messages."""
+    import glob
+
+    from ser_amd.data_loader import RAVDESS_EMOTIONS, label_for_file, labels_for_files, sorted_glob
+
+    for actor in (1, 2, 10):
+        d = tmp_path / f"Actor_{actor:02d}"
+        d.mkdir()
+        for emo in range(1, 9):
+            (d / f"03-01-{emo:02d}-01-01-01-{actor:02d}.wav").touch()
+        for odd in (".hidden.wav", "notes.txt", "weird.wav", "a-b.wav", "03-01-99-01-01-01-01.wav"):
+            (d / odd).touch()
+    (tmp_path / "Actor_not_a_directory").touch()
+    (tmp_path / "Other").mkdir()
+    (tmp_path / "Other" / "03-01-03-01-01-01-01.wav").touch()
+    patterns = [tmp_path / "Actor_*" / "*.wav", tmp_path / "Actor_*" / ".*", tmp_path / "*" / "*.wav",
+                tmp_path / "Actor_01" / "*.wav", tmp_path / "Actor_0[12]" / "03-01-0?-*.wav", tmp_path / "none*" / "*.wav",
+                tmp_path / "**" / "*.wav", tmp_path / "Actor_01" / "notes.txt", tmp_path / "Actor_*"]
+    for pattern in patterns:
+        assert sorted_glob(str(pattern)) == sorted(glob.glob(str(pattern))), pattern
+    files = sorted_glob(str(tmp_path / "*" / "*.wav"))
+    observed = set(RAVDESS_EMOTIONS.values()) - {"neutral"}
+    wanted, errors = [], []
+    for f in files:
+        label, error = label_for_file(f, observed, RAVDESS_EMOTIONS)
+        if error is not None:
+            errors.append(error)
+        elif label is not None:
+            wanted.append((f, label))
+    assert labels_for_files(files, observed, RAVDESS_EMOTIONS) == (wanted, errors)
+    assert len(errors) == 6 and len(wanted) == 3 * 7 + 1     # weird.wav, a-b.wav per actor; code 99 and neutral dropped silently

@@ -282,3 +282,28 @@ def test_host_buffer_streams_in_chunks_with_the_whole_buffer_result():
         np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
     with pytest.raises(ValueError, match="outside the audio buffer"):
         features_from_host(eng, audio, np.array([audio.size - 10]), np.array([48000]), 16000, flags)
+
+
+@pytest.mark.gpu
+def test_staged_matrix_to_host_equals_the_plain_copy(monkeypatch):
+    """``FeatureEngine.to_host_float64`` (pinned chunks + memcpy team) returns what ``.double().cpu()`` returns:
+    every chunk boundary, a last partial chunk, float32 and float64 inputs, NaN rows (failed files) kept."""
+    import torch
+
+    from ser_amd.engine import FeatureEngine, get_engine
+
+    eng = get_engine()
+    gen = torch.Generator(device=eng.device).manual_seed(5)
+    monkeypatch.setattr(FeatureEngine, "STAGED_TO_HOST_BYTES", 1 << 16)
+    for rows, dtype in ((46080, torch.float32), (7001, torch.float64), (12, torch.float32), (0, torch.float32)):
+        m = torch.randn((rows, 187), generator=gen, device=eng.device, dtype=dtype)
+        if rows > 5:
+            m[3] = float("nan")
+        got = eng.to_host_float64(m)
+        want = m.double().cpu().numpy()
+        assert got.dtype == np.float64 and got.shape == want.shape and got.flags.writeable and got.flags.c_contiguous
+        assert np.array_equal(got, want, equal_nan=True)
+    # small chunks: many trips round the pinned ring
+    monkeypatch.setattr(FeatureEngine, "STAGED_CHUNK_BYTES", (1 << 20) + 4096)
+    m = torch.randn((30011, 187), generator=gen, device=eng.device)
+    assert np.array_equal(eng.to_host_float64(m), m.double().cpu().numpy())
