@@ -278,6 +278,20 @@ int serhip_read_wav_batch(const char* paths_blob, const int64_t* path_offset, in
  * workers open files one by one); exists so that the per-file cost of a 100k-file corpus is not Python's. */
 int serhip_stat_files(const char* paths_blob, const int64_t* path_offset, int64_t n_files, int threads, int64_t* sizes);
 
+/* FLAC decoding on the host (no GPU touched): the reference reads .flac through librosa.load -> soundfile, with an
+ * explicit soundfile fallback (ser/_internal/utils/audio_utils.py:99-154); this library decodes the stream itself
+ * (ser_amd/csrc/flac_decoder.hpp, RFC 9639: every subframe type, both Rice code books, the stereo modes, wasted bits,
+ * variable block size, leading ID3v2 tags).  Lossless, so the result is the encoder's PCM bit for bit; every frame's
+ * CRC-8 / CRC-16 is checked and, with verify_md5 != 0, the MD5 signature of STREAMINFO.  A stream that fails a check
+ * is an error (SERHIP_E_INVALID with a message), never a partial result.
+ *   serhip_flac_probe   STREAMINFO: sample rate, channels (1..8), bits per sample (4..32), frames (0 = unknown)
+ *   serhip_flac_decode  out = interleaved int32 samples [capacity_frames][channels] (sign-extended, NOT scaled), or
+ *                       NULL to count the frames of a stream whose STREAMINFO does not say; *frames_decoded on return */
+int serhip_flac_probe(const void* bytes, int64_t n_bytes, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample,
+                      int64_t* total_frames);
+int serhip_flac_decode(const void* bytes, int64_t n_bytes, int32_t* out, int64_t capacity_frames, int verify_md5,
+                       int64_t* frames_decoded);
+
 /* memcpy of one large host buffer by a team of threads: pageable caller memory (a numpy array) -> pinned staging
  * at more than one core's copy bandwidth, so that staging keeps up with the H2D DMA behind it (the reference has
  * no counterpart: its arrays never leave the host). */

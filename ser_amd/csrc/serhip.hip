@@ -36,6 +36,7 @@ typedef enum { ncclFloat32 = 7 } ncclDataType_t;
 #include "kernels_project.hpp"
 #include "kernels_whisper.hpp"
 #include "tables.hpp"
+#include "flac_decoder.hpp"
 #include "wav_reader.hpp"
 
 using namespace serhip;
@@ -1536,6 +1537,40 @@ int serhip_parallel_memcpy(void* dst, const void* src, int64_t bytes, int thread
         const int64_t at = i * piece;
         std::memcpy(static_cast<char*>(dst) + at, static_cast<const char*>(src) + at, static_cast<size_t>(std::min(piece, bytes - at)));
     });
+    return SERHIP_OK;
+}
+
+int serhip_flac_probe(const void* bytes, int64_t n_bytes, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample,
+                      int64_t* total_frames) {
+    if (!bytes || n_bytes < 0) return fail(SERHIP_E_INVALID, "serhip_flac_probe: NULL or negative-length input");
+    flac::StreamInfo info;
+    std::string err;
+    if (!flac::parse_stream_info(static_cast<const uint8_t*>(bytes), static_cast<size_t>(n_bytes), &info, &err))
+        return fail(SERHIP_E_INVALID, "serhip_flac_probe: " + err);
+    if (sample_rate) *sample_rate = info.sample_rate;
+    if (channels) *channels = info.channels;
+    if (bits_per_sample) *bits_per_sample = info.bits;
+    if (total_frames) *total_frames = info.total_frames;
+    return SERHIP_OK;
+}
+
+int serhip_flac_decode(const void* bytes, int64_t n_bytes, int32_t* out, int64_t capacity_frames, int verify_md5,
+                       int64_t* frames_decoded) {
+    if (!bytes || n_bytes < 0 || !frames_decoded || (out && capacity_frames < 0))
+        return fail(SERHIP_E_INVALID, "serhip_flac_decode: NULL or negative argument");
+    flac::StreamInfo info;
+    std::string err;
+    const uint8_t* p = static_cast<const uint8_t*>(bytes);
+    if (!flac::parse_stream_info(p, static_cast<size_t>(n_bytes), &info, &err))
+        return fail(SERHIP_E_INVALID, "serhip_flac_decode: " + err);
+    int64_t done = 0;
+    try {
+        if (!flac::decode(p, static_cast<size_t>(n_bytes), info, out, capacity_frames, verify_md5 != 0, &done, &err))
+            return fail(SERHIP_E_INVALID, "serhip_flac_decode: " + err);
+    } catch (const std::bad_alloc&) {
+        return fail(SERHIP_E_NOMEM, "serhip_flac_decode: out of host memory");
+    }
+    *frames_decoded = done;
     return SERHIP_OK;
 }
 

@@ -297,9 +297,14 @@ def featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers:
         t2 = time.perf_counter()
         # what the native reader does not take: the Python reader, here on the reader thread, so that the reference's
         # retries (sleeps!) and host decodes run beside the GPU work, not in front of it
-        fallback = {}
-        for i in np.flatnonzero(clips["status"] != WAV_OK):
-            fallback[int(i)] = read_fallback(jobs[lo + int(i)])
+        # (a corpus of FLAC / AIFF / 24-bit files is ALL fallback: decoded by a team of threads -- the native FLAC
+        # decoder and numpy release the GIL -- so that such a corpus is not read by one thread)
+        todo = [int(i) for i in np.flatnonzero(clips["status"] != WAV_OK)]
+        if len(todo) > 1 and host_threads(workers) > 1:
+            with ThreadPoolExecutor(max_workers=min(host_threads(workers), len(todo)), thread_name_prefix="serhip-decode") as team:
+                fallback = dict(zip(todo, team.map(lambda i: read_fallback(jobs[lo + i]), todo)))
+        else:
+            fallback = {i: read_fallback(jobs[lo + i]) for i in todo}
         clock["reader_wait_pinned_s"] += t1 - t0
         clock["reader_native_s"] += t2 - t1
         clock["reader_fallback_s"] += time.perf_counter() - t2

@@ -250,7 +250,7 @@ def test_read_audio_file(tmp_path):
     import time
 
     t0 = time.perf_counter()   # a deterministic parser verdict is not retried: no sleeping
-    with pytest.raises(AudioDecodeError, match="Error reading .*not a RIFF/WAVE file"):
+    with pytest.raises(AudioDecodeError, match="Error reading .*not a RIFF/WAVE, FLAC, AIFF or AU file"):
         read_audio_file(str(junk), audio_read_config=AudioReadConfig(max_retries=3, retry_delay_seconds=5.0))
     assert time.perf_counter() - t0 < 1.0
     adpcm = tmp_path / "adpcm.wav"

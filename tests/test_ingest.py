@@ -307,3 +307,64 @@ def test_staged_matrix_to_host_equals_the_plain_copy(monkeypatch):
     monkeypatch.setattr(FeatureEngine, "STAGED_CHUNK_BYTES", (1 << 20) + 4096)
     m = torch.randn((30011, 187), generator=gen, device=eng.device)
     assert np.array_equal(eng.to_host_float64(m), m.double().cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_loader_takes_flac_aiff_and_au_beside_wave(tmp_path, monkeypatch):
+    """The same PCM as WAV, FLAC, AIFF and AU (and A-law WAV: a lossy cousin, only finite-checked) through both
+    loaders: rows of the lossless containers are bit-equal to the WAV row -- they reach the kernels through the host
+    decoders (``audio_io.decode_bytes``), several per slab on the decode team."""
+    import audioop
+    import struct
+    import wave
+
+    import torch
+
+    from flac_writer import encode_stream
+    from ser_amd import AudioReadConfig, FeatureFlags
+    from ser_amd.data_loader import featurize_audio_jobs_device
+
+    rng = np.random.default_rng(23)
+    jobs, kinds = [], []
+    for k in range(6):
+        n = 24000 + 512 * k
+        t = np.arange(n)
+        pcm = np.rint(9000 * np.sin(2 * np.pi * (200 + 30 * k) * t / 16000) + rng.integers(-300, 300, n)).astype(np.int64)[:, None]
+        with wave.open(str(tmp_path / f"c{k}.wav"), "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(pcm.astype("<i2").tobytes())
+        frames = [{"block": 4096, "subframes": [{"type": "fixed", "order": 2, "partition_order": 3}]}] * (n // 4096)
+        if n % 4096:
+            frames = frames + [{"block": n % 4096, "subframes": [{"type": "fixed", "order": 1}]}]
+        (tmp_path / f"c{k}.flac").write_bytes(encode_stream(pcm, bits=16, rate=16000, frames=frames))
+        comm = struct.pack(">hIh", 1, n, 16) + struct.pack(">HQ", 16383 + 13, 16000 << 50)
+        ssnd = struct.pack(">II", 0, 0) + pcm.astype(">i2").tobytes()
+        body = b"AIFF" + b"COMM" + struct.pack(">I", len(comm)) + comm + b"SSND" + struct.pack(">I", len(ssnd)) + ssnd
+        (tmp_path / f"c{k}.aiff").write_bytes(b"FORM" + struct.pack(">I", len(body)) + body)
+        (tmp_path / f"c{k}.au").write_bytes(b".snd" + struct.pack(">IIIII", 24, 2 * n, 3, 16000, 1) + pcm.astype(">i2").tobytes())
+        law = audioop.lin2alaw(pcm.astype("<i2").tobytes(), 2)
+        fmt = struct.pack("<HHIIHH", 6, 1, 16000, 16000, 1, 8)
+        chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(law)) + law
+        (tmp_path / f"c{k}_alaw.wav").write_bytes(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)
+        for kind in ("wav", "flac", "aiff", "au", "alaw"):
+            name = f"c{k}_alaw.wav" if kind == "alaw" else f"c{k}.{kind}"
+            jobs.append((str(tmp_path / name), None, None))
+            kinds.append((k, kind))
+    flags = FeatureFlags(tonnetz=False)
+    cfg = AudioReadConfig(max_retries=1, retry_delay_seconds=0.0)
+    monkeypatch.setenv("SERHIP_SLAB_BYTES", str(1 << 20))
+    for pipelined in (False, True):
+        m, errs = featurize_audio_jobs_device(jobs, feature_flags=flags, audio_read_config=cfg, workers=4, pipelined=pipelined)
+        torch.cuda.synchronize()
+        rows = m.cpu().numpy()
+        assert not any(errs) and np.isfinite(rows).all()
+        by_clip = {}
+        for (k, kind), row in zip(kinds, rows):
+            by_clip.setdefault(k, {})[kind] = row
+        for k, group in by_clip.items():
+            for kind in ("flac", "aiff", "au"):
+                np.testing.assert_array_equal(group[kind], group["wav"], err_msg=f"clip {k} {kind} pipelined={pipelined}")
+            assert not np.array_equal(group["alaw"], group["wav"])      # companded: close, not equal
+            assert np.abs(group["alaw"][:40] - group["wav"][:40]).max() < 25.0
