@@ -12,6 +12,7 @@
 // FLAC, resynchronisation after a damaged frame (a damaged file is an error).
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -108,32 +109,31 @@ private:
 
 // ---- CRCs of the frame layer: CRC-8 (x^8 + x^2 + x + 1) and CRC-16 (x^16 + x^15 + x^2 + 1), both initialised with 0
 inline uint8_t crc8(const uint8_t* p, size_t n) {
-    static uint8_t table[256];
-    static bool ready = false;
-    if (!ready) {
+    // (a function-local static initialised by a lambda: thread-safe, the decode team calls this concurrently)
+    static const std::array<uint8_t, 256> table = [] {
+        std::array<uint8_t, 256> t{};
         for (int i = 0; i < 256; ++i) {
             uint8_t c = static_cast<uint8_t>(i);
             for (int k = 0; k < 8; ++k) c = static_cast<uint8_t>((c & 0x80) ? (c << 1) ^ 0x07 : (c << 1));
-            table[i] = c;
+            t[i] = c;
         }
-        ready = true;
-    }
+        return t;
+    }();
     uint8_t c = 0;
     for (size_t i = 0; i < n; ++i) c = table[c ^ p[i]];
     return c;
 }
 
 inline uint16_t crc16(const uint8_t* p, size_t n) {
-    static uint16_t table[256];
-    static bool ready = false;
-    if (!ready) {
+    static const std::array<uint16_t, 256> table = [] {
+        std::array<uint16_t, 256> t{};
         for (int i = 0; i < 256; ++i) {
             uint16_t c = static_cast<uint16_t>(i << 8);
             for (int k = 0; k < 8; ++k) c = static_cast<uint16_t>((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1));
-            table[i] = c;
+            t[i] = c;
         }
-        ready = true;
-    }
+        return t;
+    }();
     uint16_t c = 0;
     for (size_t i = 0; i < n; ++i) c = static_cast<uint16_t>((c << 8) ^ table[(c >> 8) ^ p[i]]);
     return c;
@@ -302,11 +302,14 @@ inline bool decode_subframe(BitReader& br, int block, int bps, int64_t* out, std
         if (order > block) { *err = "FLAC fixed predictor order exceeds the block"; return false; }
         for (int i = 0; i < order; ++i) out[i] = br.read_signed(bps);
         if (!decode_residual(br, block, order, out, err)) return false;
+        // (unsigned arithmetic: a damaged stream may drive these sums past 64 bits, which must wrap, not be undefined;
+        // such a frame fails its CRC afterwards)
+        uint64_t* u = reinterpret_cast<uint64_t*>(out);
         switch (order) {
-            case 1: for (int i = 1; i < block; ++i) out[i] += out[i - 1]; break;
-            case 2: for (int i = 2; i < block; ++i) out[i] += 2 * out[i - 1] - out[i - 2]; break;
-            case 3: for (int i = 3; i < block; ++i) out[i] += 3 * out[i - 1] - 3 * out[i - 2] + out[i - 3]; break;
-            case 4: for (int i = 4; i < block; ++i) out[i] += 4 * out[i - 1] - 6 * out[i - 2] + 4 * out[i - 3] - out[i - 4]; break;
+            case 1: for (int i = 1; i < block; ++i) u[i] += u[i - 1]; break;
+            case 2: for (int i = 2; i < block; ++i) u[i] += 2 * u[i - 1] - u[i - 2]; break;
+            case 3: for (int i = 3; i < block; ++i) u[i] += 3 * u[i - 1] - 3 * u[i - 2] + u[i - 3]; break;
+            case 4: for (int i = 4; i < block; ++i) u[i] += 4 * u[i - 1] - 6 * u[i - 2] + 4 * u[i - 3] - u[i - 4]; break;
             default: break;
         }
     } else if (type >= 32) {               // LPC, order 1..32
@@ -321,9 +324,9 @@ inline bool decode_subframe(BitReader& br, int block, int bps, int64_t* out, std
         for (int j = 0; j < order; ++j) coef[j] = br.read_signed(precision);
         if (!decode_residual(br, block, order, out, err)) return false;
         for (int i = order; i < block; ++i) {
-            int64_t sum = 0;
-            for (int j = 0; j < order; ++j) sum += coef[j] * out[i - 1 - j];
-            out[i] += sum >> shift;
+            uint64_t sum = 0;
+            for (int j = 0; j < order; ++j) sum += static_cast<uint64_t>(coef[j]) * static_cast<uint64_t>(out[i - 1 - j]);
+            out[i] = static_cast<int64_t>(static_cast<uint64_t>(out[i]) + static_cast<uint64_t>(static_cast<int64_t>(sum) >> shift));
         }
     } else {
         *err = "reserved FLAC subframe type";
@@ -331,7 +334,7 @@ inline bool decode_subframe(BitReader& br, int block, int bps, int64_t* out, std
     }
     if (br.failed()) { *err = "FLAC frame ends inside a subframe"; return false; }
     if (wasted)
-        for (int i = 0; i < block; ++i) out[i] = out[i] * (static_cast<int64_t>(1) << wasted);
+        for (int i = 0; i < block; ++i) out[i] = static_cast<int64_t>(static_cast<uint64_t>(out[i]) << wasted);
     return true;
 }
 
@@ -414,15 +417,15 @@ inline bool decode(const uint8_t* p, size_t n, const StreamInfo& info, int32_t* 
         int64_t* c0 = work.data();
         int64_t* c1 = work.data() + 65536;
         if (ch_code == 8) {            // left, side
-            for (int i = 0; i < block; ++i) c1[i] = c0[i] - c1[i];
+            for (int i = 0; i < block; ++i) c1[i] = static_cast<int64_t>(static_cast<uint64_t>(c0[i]) - static_cast<uint64_t>(c1[i]));
         } else if (ch_code == 9) {     // side, right
-            for (int i = 0; i < block; ++i) c0[i] += c1[i];
+            for (int i = 0; i < block; ++i) c0[i] = static_cast<int64_t>(static_cast<uint64_t>(c0[i]) + static_cast<uint64_t>(c1[i]));
         } else if (ch_code == 10) {    // mid, side
             for (int i = 0; i < block; ++i) {
                 const int64_t side = c1[i];
-                const int64_t mid = (c0[i] * 2) | (side & 1);
-                c0[i] = (mid + side) >> 1;
-                c1[i] = (mid - side) >> 1;
+                const int64_t mid = static_cast<int64_t>((static_cast<uint64_t>(c0[i]) << 1) | static_cast<uint64_t>(side & 1));
+                c0[i] = static_cast<int64_t>(static_cast<uint64_t>(mid) + static_cast<uint64_t>(side)) >> 1;
+                c1[i] = static_cast<int64_t>(static_cast<uint64_t>(mid) - static_cast<uint64_t>(side)) >> 1;
             }
         }
         int take = block;

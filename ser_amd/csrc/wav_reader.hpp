@@ -137,7 +137,11 @@ void parallel_for(int64_t n, int threads, F fn) {
 }
 
 // int(float(seconds) * rate) of the Python reader (audio_io.read_raw_clip): truncation toward zero of a double product
-inline int64_t frames_of_seconds(double seconds, int64_t rate) { return static_cast<int64_t>(seconds * static_cast<double>(rate)); }
+inline int64_t frames_of_seconds(double seconds, int64_t rate) {
+    const double frames = seconds * static_cast<double>(rate);
+    if (!(frames < 4.0e18)) return static_cast<int64_t>(4.0e18);   // "past any file"; the conversion of a larger double is undefined
+    return frames <= 0.0 ? 0 : static_cast<int64_t>(frames);
+}
 
 // One file -> its region [region, region + capacity) of the slab.  Returns the status; fills `clip` on SERHIP_WAV_OK.
 inline int read_one_wav(const char* path, double start_seconds, double duration_seconds, unsigned char* slab,
