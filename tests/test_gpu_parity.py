@@ -70,6 +70,56 @@ def test_driver_entry_points_in_a_fresh_process():
     assert "smoke ok" in res.stdout
 
 
+def test_plain_c_host_over_the_c_abi(engine, flags, tmp_path):
+    """``examples/host_c_abi`` -- gcc, the system HIP runtime, no Python, no torch -- reads WAVE files with the
+    library's reader team, prepares and featurises them through the C ABI and prints the rows: the same bits the
+    Python host gets for the same files, and a file the device path does not take is reported, not guessed."""
+    import subprocess
+    import wave
+    from pathlib import Path
+
+    from ser_amd import AudioReadConfig
+    from ser_amd.data_loader import featurize_audio_jobs_device
+
+    exe = Path(__file__).resolve().parent.parent / "examples" / "host_c_abi"
+    assert exe.exists(), "examples/host_c_abi is built by __graft_entry__.build()"
+    rng = np.random.default_rng(31)
+    paths = []
+    for k, (channels, n) in enumerate(((1, 48000), (2, 30001), (1, 1500), (2, 2048))):
+        t = np.arange(n)[:, None]
+        pcm = np.rint(7000 * np.sin(2 * np.pi * (150 + 40 * k + 25 * np.arange(channels)) * t / 16000)
+                      + rng.integers(-200, 200, (n, channels))).astype("<i2")
+        with wave.open(str(tmp_path / f"h{k}.wav"), "wb") as w:
+            w.setnchannels(channels)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(pcm.tobytes())
+        paths.append(str(tmp_path / f"h{k}.wav"))
+    with wave.open(str(tmp_path / "wide.wav"), "wb") as w:      # 24-bit PCM: the host decoder's business
+        w.setnchannels(1)
+        w.setsampwidth(3)
+        w.setframerate(16000)
+        w.writeframes(bytes(3 * 4000))
+    args = paths[:2] + [str(tmp_path / "wide.wav"), str(tmp_path / "missing.wav")] + paths[2:]
+    res = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = res.stdout.strip().split("\n")
+    assert len(lines) == len(args)
+    assert lines[2].endswith("SKIPPED status=1") and lines[3].endswith("SKIPPED status=2")     # HOST_DECODE, IO
+    rows = {}
+    for line in lines:
+        parts = line.split(" ")
+        if parts[1] != "SKIPPED":
+            assert int(parts[2]) == 16000 and int(parts[3]) == 187
+            rows[parts[0]] = np.asarray([np.float32(v) for v in parts[4:]], dtype=np.float32)
+    want, errs = featurize_audio_jobs_device([(p, None, None) for p in paths], feature_flags=flags,
+                                             audio_read_config=AudioReadConfig(), workers=2)
+    assert not any(errs)
+    want = want.cpu().numpy()
+    for i, p in enumerate(paths):
+        np.testing.assert_array_equal(rows[p], want[i], err_msg=p)
+
+
 def test_config3_clips_batch(engine, flags):
     """Config 3 shape (3 s clips @16 kHz, harmonics + noise), 24 clips."""
     from ser_amd.synth import harmonic_clips
