@@ -8,6 +8,7 @@ is one pass of the hot path over the rank's batch (inputs already resident in HB
 for N > 1, the gather; the gather of step k is left in flight on RCCL's stream while the
 kernels of step k + 1 run, and is waited for before the next gather and before the clock stops.
 
+    python bench.py                     # N = 1, 200 steps after 5 warm-up steps
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -118,8 +119,10 @@ def cpu_baseline(n_clips: int, workers: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: 200 steps of ~3.6 ms = a timed region of ~0.7 s (long enough for an outside sampler of GPU activity to
+    # see it, and for the mean to sit within the box-to-box spread rather than within one step's jitter)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips-per-gpu", type=int, default=CLIPS_PER_GPU)
     ap.add_argument("--cpu-clips", type=int, default=4000, help="clips in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=8)

@@ -35,7 +35,7 @@ def main():
         if on:
             keep.append(line)
     (dst / f"{tag}_summary.txt").write_text(
-        f"# rocprofv3 --kernel-trace --stats + PMC passes of `python3 bench.py --steps 10 --warmup 2 --cpu-clips 0` "
+        f"# rocprofv3 --kernel-trace --stats + PMC passes of `python3 bench.py --steps 50 --warmup 5 --cpu-clips 0` "
         f"(scripts/profile_gpu.sh {tag})\n# per-launch averages; one launch = 12 500 clips = 1 175 000 STFT frames\n"
         + "\n".join(keep) + "\n")
     bench = ROOT / "gpurun_out" / f"bench_{tag}.json"

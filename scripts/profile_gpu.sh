@@ -8,8 +8,9 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-# 12 launches per kernel: the first (cold scratch pages, cold tables: +35 % on k_project_frames) weighs 1/12 in the averages
-BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --cpu-clips 0"
+# 55 launches per kernel: the first ones (cold scratch pages, cold tables, clocks still ramping: +35 % on the first
+# k_project_frames, +5 % on the first ten steps as a whole) weigh little in the averages
+BENCH="python3 $ROOT/bench.py --steps 50 --warmup 5 --cpu-clips 0"
 # the plain run first (no profiler): the bench line with the CPU baseline
 ( cd "$ROOT" && timeout -k 10 400 python3 bench.py > "$ROOT/gpurun_out/bench_$TAG.json" 2> "$ROOT/gpurun_out/bench_$TAG.err" ) || { echo "bench failed"; tail -5 "$ROOT/gpurun_out/bench_$TAG.err"; exit 1; }
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }

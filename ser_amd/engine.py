@@ -115,14 +115,18 @@ class FeatureEngine:
             events[k].record(stream)
 
         with torch.cuda.device(self.device):
-            for k in range(min(PINNED_BUFFERS, n_chunks)):
-                issue(k)
-            for k in range(n_chunks):
-                events.pop(k).synchronize()
-                lo, hi = k * chunk, min(nbytes, (k + 1) * chunk)
-                parallel_memcpy(out.ctypes.data + lo, pinned[k % PINNED_BUFFERS].data_ptr(), hi - lo)
-                if k + PINNED_BUFFERS < n_chunks:
-                    issue(k + PINNED_BUFFERS)   # into the buffer that has just been drained
+            try:
+                for k in range(min(PINNED_BUFFERS, n_chunks)):
+                    issue(k)
+                for k in range(n_chunks):
+                    events.pop(k).synchronize()
+                    lo, hi = k * chunk, min(nbytes, (k + 1) * chunk)
+                    parallel_memcpy(out.ctypes.data + lo, pinned[k % PINNED_BUFFERS].data_ptr(), hi - lo)
+                    if k + PINNED_BUFFERS < n_chunks:
+                        issue(k + PINNED_BUFFERS)   # into the buffer that has just been drained
+            finally:
+                for ev in events.values():          # on an error: no copy may still be writing the shared ring
+                    ev.synchronize()
         return out
 
     # ------------------------------------------------------------------ hot path
