@@ -52,7 +52,7 @@ case "$MODE" in
     [ -f "gpurun_out/ingest_overlap_$TAG.json" ] && cp "gpurun_out/ingest_overlap_$TAG.json" "profiles/${TAG}_ingest_overlap.json"
     [ -f "gpurun_out/rehearsal_$TAG.json" ] && cp "gpurun_out/rehearsal_$TAG.json" "profiles/${TAG}_rehearsal_2ranks_one_gpu.json"
     for k in harmonic_3000 noisy_1500 windows_3600; do
-      [ -f "gpurun_out/parity_${k}_$TAG.json" ] && cp "gpurun_out/parity_${k}_$TAG.json" "profiles/${TAG}_parity_${k}.json"
+      if [ -f "gpurun_out/parity_${k}_$TAG.json" ]; then cp "gpurun_out/parity_${k}_$TAG.json" "profiles/${TAG}_parity_${k}.json"; fi
     done
     ;;
   *) echo "usage: $0 cpu | gpu <tag> | parity <tag> | collect <tag>"; exit 2 ;;
