@@ -79,6 +79,39 @@ def test_mfcc_is_ortho_dct_of_log_mel():
     np.testing.assert_allclose(m, basis @ logmel.astype(np.float64), rtol=1e-5, atol=1e-3)
 
 
+def test_log_mel_and_mfcc_chain_matches_hf_spectrogram_end_to_end():
+    """The whole mel / MFCC lane of ``dsp.py:106-125`` against ONE call of an independent implementation:
+    ``transformers.audio_utils.spectrogram`` (its own framing, zero padding, windowing, rfft, mel projection and dB
+    conversion with an 80 dB range against the global maximum) -- not piece by piece as above.  Pins the composition:
+    centre padding with zeros, hop 512, the frame count, power (not magnitude) into the mel bank, ``top_db`` against the
+    segment-global maximum, and the time means the reference takes."""
+    import scipy.fft
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+
+    rng = np.random.default_rng(12)
+    bank = mel_filter_bank(num_frequency_bins=1025, num_mel_filters=128, min_frequency=0.0, max_frequency=SR / 2,
+                           sampling_rate=SR, norm="slaney", mel_scale="slaney")
+    window = window_function(2048, "hann", periodic=True)
+    for n, loud in ((48000, 1.0), (21937, 0.05), (2048, 1.0)):
+        t = np.arange(n) / SR
+        y = (loud * (0.6 * np.sin(2 * np.pi * 233.0 * t) + 0.3 * np.sin(2 * np.pi * 1470.0 * t) * np.hanning(n))
+             + 1e-3 * rng.standard_normal(n)).astype(np.float32)
+        y[: n // 5] *= 1e-4                                    # a quiet stretch: frames that top_db clips
+        power = spectrogram(y.astype(np.float64), window, frame_length=2048, hop_length=512, fft_length=2048, power=2.0,
+                            center=True, pad_mode="constant", mel_filters=bank, mel_floor=0.0, dtype=np.float64)
+        logmel = spectrogram(y.astype(np.float64), window, frame_length=2048, hop_length=512, fft_length=2048, power=2.0,
+                             center=True, pad_mode="constant", mel_filters=bank, mel_floor=1e-10, log_mel="dB",
+                             reference=1.0, min_value=1e-10, db_range=80.0, dtype=np.float64)
+        assert power.shape == logmel.shape == (128, 1 + n // 512)
+        ours_power = lr.melspectrogram(y, sr=SR, n_fft=2048)
+        np.testing.assert_allclose(ours_power, power, rtol=2e-4, atol=1e-6 * power.max())
+        ours_db = lr.power_to_db(ours_power)
+        assert n < 4096 or (ours_db == ours_db.max() - 80.0).any()          # the clip is exercised on the long clips
+        np.testing.assert_allclose(ours_db, logmel, rtol=0, atol=2e-3)
+        want_mfcc = scipy.fft.dct(logmel, type=2, norm="ortho", axis=0)[:40].mean(axis=1)
+        np.testing.assert_allclose(lr.mfcc(y, sr=SR, n_mfcc=40, n_fft=2048).mean(axis=1), want_mfcc, rtol=1e-4, atol=2e-3)
+
+
 def test_pure_tone_tuning_and_chroma_known_answer():
     """A 452.9 Hz tone is A4 + 50 cents: tuning estimate -0.5/+0.5 boundary aside, a 446.4 Hz
     tone (+25 cents) must estimate +0.25 and put the chroma peak on A (index 9, C-based)."""
