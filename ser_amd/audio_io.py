@@ -112,6 +112,13 @@ def _int_pcm_to_float(raw: bytes, bits: int, *, big_endian: bool, unsigned8: boo
     raise AudioDecodeError(f"unsupported PCM width ({bits} bits)")
 
 
+def _float_payload(raw: bytes, dtype: str) -> NDArray[np.float32]:
+    """IEEE float samples -> float32; a float64 beyond float32's range becomes inf (then scrubbed like any other
+    non-finite sample, audio_utils.py:53-55) without a numpy warning per file."""
+    with np.errstate(over="ignore", invalid="ignore"):
+        return np.frombuffer(raw, dtype=dtype).astype(np.float32)
+
+
 def _companded_to_float(raw: bytes, table: NDArray[np.int16]) -> NDArray[np.float32]:
     return table[np.frombuffer(raw, dtype=np.uint8)].astype(np.float32) / np.float32(32768.0)
 
@@ -194,7 +201,7 @@ def _parse_aiff(data: bytes):
     elif kind in (b"fl32", b"FL32", b"fl64", b"FL64"):
         item = 4 if kind.lower() == b"fl32" else 8
         usable = min(len(sound), n_frames * channels * item) // (channels * item) * (channels * item)
-        x = np.frombuffer(sound[:usable], dtype=">f4" if item == 4 else ">f8").astype(np.float32)
+        x = _float_payload(sound[:usable], ">f4" if item == 4 else ">f8")
     elif kind in (b"alaw", b"ALAW", b"ulaw", b"ULAW"):
         usable = min(len(sound), n_frames * channels) // channels * channels
         x = _companded_to_float(sound[:usable], _ALAW16 if kind.lower() == b"alaw" else _ULAW16)
@@ -224,7 +231,7 @@ def _parse_au(data: bytes):
     elif encoding in (6, 7):
         item = 4 if encoding == 6 else 8
         frame = channels * item
-        x = np.frombuffer(body[: len(body) // frame * frame], dtype=">f4" if item == 4 else ">f8").astype(np.float32)
+        x = _float_payload(body[: len(body) // frame * frame], ">f4" if item == 4 else ">f8")
     else:
         raise AudioDecodeError(f"unsupported AU encoding {encoding}")
     if channels > 1:
@@ -236,7 +243,21 @@ _LOSSY_MAGIC = ((b"OggS", "Ogg (Vorbis / Opus / Ogg-FLAC)"), (b"\xff\xfb", "MP3"
 
 
 def decode_bytes(data: bytes):
-    """Decode one file's bytes by container magic -> (float32 [frames] or [frames, channels], sample_rate)."""
+    """Decode one file's bytes by container magic -> (float32 [frames] or [frames, channels], sample_rate).
+    Whatever a parser trips over in damaged bytes (a short header, a size that does not divide, an absurd count) is
+    a deterministic verdict on those bytes and leaves as ``AudioDecodeError`` -- never as an exception the caller's
+    retry loop would take for a transient failure."""
+    try:
+        return _decode_bytes(data)
+    except AudioDecodeError:
+        raise
+    except MemoryError:
+        raise
+    except (struct.error, ValueError, IndexError, OverflowError, ZeroDivisionError, TypeError) as err:
+        raise AudioDecodeError(f"damaged audio file ({type(err).__name__}: {err})") from err
+
+
+def _decode_bytes(data: bytes):
     head = bytes(data[:12])
     if head[:4] in (b"RIFF", b"RF64", b"BW64") and head[8:12] == b"WAVE":
         return _parse_wave(data)
@@ -299,7 +320,7 @@ def _parse_wave(data: bytes):
     elif code == 3 and bits == 32:
         x = np.frombuffer(raw, dtype="<f4").astype(np.float32)
     elif code == 3 and bits == 64:
-        x = np.frombuffer(raw, dtype="<f8").astype(np.float32)
+        x = _float_payload(raw, "<f8")
     elif code == 6 and bits == 8:
         x = _companded_to_float(raw, _ALAW16)
     elif code == 7 and bits == 8:
