@@ -96,10 +96,17 @@ class FeatureEngine:
         nbytes = wide.numel() * 8
         if nbytes < self.STAGED_TO_HOST_BYTES:
             return wide.cpu().numpy()
-        from .ingest import PINNED_BUFFERS, ingest_buffers, parallel_memcpy
+        from .ingest import ingest_buffers
 
         out = np.empty(tuple(wide.shape), dtype=np.float64)
         buffers = ingest_buffers(self)
+        with buffers.lock:
+            return self._staged_to_host(buffers, wide, out, nbytes)
+
+    def _staged_to_host(self, buffers, wide, out, nbytes: int) -> np.ndarray:
+        from .ingest import PINNED_BUFFERS, parallel_memcpy
+
+        torch = self._torch
         buffers.ensure(min(nbytes, self.STAGED_CHUNK_BYTES))
         pinned = buffers.pinned
         chunk = min(self.STAGED_CHUNK_BYTES, *(int(p.numel()) for p in pinned))

@@ -21,8 +21,12 @@ and featurised while the next chunk is staged.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import gc
 import os
+import sys
+import threading
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from ctypes import POINTER, c_int64, c_void_p
@@ -41,6 +45,47 @@ DEFAULT_SLAB_BYTES = 128 << 20     # file bytes per slab (override: SERHIP_SLAB_
 DEFAULT_CHUNK_BYTES = 64 << 20     # host-buffer bytes per staged chunk (override: SERHIP_CHUNK_BYTES)
 PINNED_BUFFERS = 3                 # one being read into, one in flight to the GPU, one spare
 DEVICE_BUFFERS = 2                 # one being copied into, one being read by the kernels
+
+
+_interpreter_lock = threading.Lock()
+_interpreter_depth = 0
+_interpreter_saved: tuple[bool, float] | None = None
+
+
+@contextlib.contextmanager
+def interpreter_tuned_for_the_pipeline():
+    """Two process-wide interpreter settings for the duration of a pipelined call, restored when the LAST concurrent
+    call leaves (a depth count under a lock: two overlapping calls must not restore each other's "saved" values):
+
+    * the cyclic garbage collector is held off -- building the per-call tables allocates a few containers per 100 k
+      files, enough to trip a full collection every other call, and a full collection walks every object torch /
+      sklearn / numpy have created: 50-60 ms, as long as featurising 46 000 files takes (calls alternated between 62
+      and 115 ms; 60-67 ms with the collector off);
+    * the thread switch interval is lowered from CPython's 5 ms -- several slabs' worth -- to 20 us
+      (``SERHIP_SWITCH_INTERVAL``): the reader thread returns from its native call about once a millisecond and must
+      re-acquire the GIL to hand over the slab, and a thread that wants the GIL waits up to the interval for the
+      running one to yield."""
+    global _interpreter_depth, _interpreter_saved
+    with _interpreter_lock:
+        if _interpreter_depth == 0:
+            _interpreter_saved = (gc.isenabled(), sys.getswitchinterval())
+            gc.disable()
+            try:
+                sys.setswitchinterval(float(os.environ.get("SERHIP_SWITCH_INTERVAL", 2e-5)))
+            except ValueError:
+                pass
+        _interpreter_depth += 1
+    try:
+        yield
+    finally:
+        with _interpreter_lock:
+            _interpreter_depth -= 1
+            if _interpreter_depth == 0 and _interpreter_saved is not None:
+                was_enabled, interval = _interpreter_saved
+                _interpreter_saved = None
+                sys.setswitchinterval(interval)
+                if was_enabled:
+                    gc.enable()
 
 
 def host_threads(requested: int | None = None) -> int:
@@ -166,6 +211,9 @@ class IngestBuffers:
         self.pinned: list = []
         self.device: list = []
         self.last_use = None     # event on the compute stream: everything that read self.device has been enqueued before it
+        # one user of the ring at a time: a pipelined call, a staged host buffer or a staged copy back to the host
+        # (two threads loading data through one engine take turns instead of overwriting each other's slabs)
+        self.lock = threading.RLock()
 
     def ensure(self, nbytes: int) -> None:
         torch = self.torch
@@ -249,21 +297,12 @@ def featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers:
     computing overlapped slab by slab.  The caller (``data_loader.featurize_audio_jobs_device``) supplies the pieces
     that are not specific to the pipeline: ``read_fallback(job)`` (the Python reader), ``run_host_group`` (host-decoded
     clips of one rate) and ``bisect`` (its failure-isolating retry)."""
-    import gc
+    from .engine import get_engine
 
-    # The cyclic collector is held off for the duration of the call (restored on the way out): building the per-call
-    # tables allocates a few containers per 100 k files, enough to trip a full collection every other call, and a full
-    # collection walks every object torch / sklearn / numpy have created -- 50-60 ms, as long as featurising
-    # 46 000 files takes (measured: calls alternated between 62 and 115 ms; 62-66 ms with the collector off).
-    gc_was_enabled = gc.isenabled()
-    gc.disable()
-    try:
+    with interpreter_tuned_for_the_pipeline(), ingest_buffers(get_engine()).lock:
         _featurize_jobs_pipelined(jobs, feature_flags=feature_flags, audio_read_config=audio_read_config, workers=workers,
                                   matrix=matrix, errors=errors, read_fallback=read_fallback, run_host_group=run_host_group,
                                   bisect=bisect, stats=stats)
-    finally:
-        if gc_was_enabled:
-            gc.enable()
 
 
 def _featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers: int, matrix, errors,
@@ -381,18 +420,7 @@ def _featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers
                     run_host_group(lo, rate, members)
                 clock["main_issue_s"] += time.perf_counter() - t1
 
-    # Two Python threads take turns here (the reader thread returns from its native call about once a millisecond
-    # and must re-acquire the GIL to hand over the slab).  CPython makes a thread that wants the GIL wait up to the
-    # switch interval -- 5 ms by default, several slabs' worth -- for a running thread to yield, so for the duration
-    # of the loop the interval is lowered (process-wide, restored on the way out).
-    import sys
-
-    switch_interval = sys.getswitchinterval()
-    sys.setswitchinterval(float(os.environ.get("SERHIP_SWITCH_INTERVAL", 2e-5)))
-    try:
-        _run_slabs()
-    finally:
-        sys.setswitchinterval(switch_interval)
+    _run_slabs()
     if stats is not None:
         stats.update(clock)
         stats["total_s"] = time.perf_counter() - t_enter
@@ -402,6 +430,13 @@ def _featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers
 # ------------------------------------------------------------------------------------------ host buffer -> features
 def features_from_host(engine, audio: np.ndarray, seg_offset: np.ndarray, seg_len: np.ndarray, sample_rate: int, flags,
                        *, out=None, chunk_bytes: int | None = None, threads: int | None = None, stats: dict | None = None):
+    with ingest_buffers(engine).lock:
+        return _features_from_host(engine, audio, seg_offset, seg_len, sample_rate, flags, out=out, chunk_bytes=chunk_bytes,
+                                   threads=threads, stats=stats)
+
+
+def _features_from_host(engine, audio: np.ndarray, seg_offset: np.ndarray, seg_len: np.ndarray, sample_rate: int, flags,
+                        *, out=None, chunk_bytes: int | None = None, threads: int | None = None, stats: dict | None = None):
     """``engine.features`` for float32 audio in pageable host memory with non-decreasing segment offsets: the buffer
     goes to the GPU chunk by chunk (parallel memcpy into pinned staging, asynchronous H2D on the copy stream) and
     the segments of a chunk are featurised while the next chunk is staged.  Returns the ``[n_seg, D]`` device tensor."""

@@ -368,3 +368,45 @@ def test_loader_takes_flac_aiff_and_au_beside_wave(tmp_path, monkeypatch):
                 np.testing.assert_array_equal(group[kind], group["wav"], err_msg=f"clip {k} {kind} pipelined={pipelined}")
             assert not np.array_equal(group["alaw"], group["wav"])      # companded: close, not equal
             assert np.abs(group["alaw"][:40] - group["wav"][:40]).max() < 25.0
+
+
+def test_interpreter_settings_are_restored_by_the_last_concurrent_call():
+    """``interpreter_tuned_for_the_pipeline`` (GC held off, short thread switch interval) nests and overlaps: whatever
+    order concurrent calls leave in, the process ends with the settings it started with."""
+    import gc
+    import sys
+    import threading
+
+    from ser_amd.ingest import interpreter_tuned_for_the_pipeline
+
+    before = (gc.isenabled(), sys.getswitchinterval())
+    assert before[0]
+    inside, release_a, release_b = threading.Barrier(3), threading.Event(), threading.Event()
+
+    def call(release):
+        with interpreter_tuned_for_the_pipeline():
+            assert not gc.isenabled() and sys.getswitchinterval() < 1e-3
+            inside.wait()
+            release.wait()
+
+    a = threading.Thread(target=call, args=(release_a,))
+    b = threading.Thread(target=call, args=(release_b,))
+    a.start(); b.start()
+    inside.wait()
+    release_a.set(); a.join()
+    assert not gc.isenabled() and sys.getswitchinterval() < 1e-3      # b is still inside
+    release_b.set(); b.join()
+    assert (gc.isenabled(), sys.getswitchinterval()) == before
+    with interpreter_tuned_for_the_pipeline():
+        with pytest.raises(RuntimeError):
+            with interpreter_tuned_for_the_pipeline():
+                raise RuntimeError("boom")
+        assert not gc.isenabled()
+    assert (gc.isenabled(), sys.getswitchinterval()) == before
+    gc.disable()                                                       # a caller that runs with the collector off keeps it off
+    try:
+        with interpreter_tuned_for_the_pipeline():
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
