@@ -247,7 +247,10 @@ int serhip_tuning_from_peaks(serhip_plan* plan, const float* pitch_mag, const in
  *   start_seconds / duration_seconds  [n_files] or NULL; NaN = not given (whole file).  Frame range as in the
  *                 reference's segment reads: first = (int64)(start * rate), count = (int64)(duration * rate)
  *   dst_offset / dst_capacity  [n_files] the region of `dst` each WHOLE file is read into (header included);
- *                 regions must not overlap and should start 16-byte aligned; capacity >= the file's size
+ *                 regions should start 16-byte aligned; capacity >= the file's size.  Regions must not overlap, with
+ *                 one exception that is the point of it: CONSECUTIVE entries that name the same path and the same
+ *                 region are segments of one recording -- the file is read once and every entry selects its own
+ *                 frames from it (a manifest with thousands of utterances of one long file costs one read)
  *   clips         [n_files] out: per file a status and, for SERHIP_WAV_OK, where its selected frames sit in `dst`
  *                 (raw_offset is a multiple of the sample size: what serhip_prepare_audio's clip_raw_offset takes)
  * Every status other than SERHIP_WAV_OK means "not handled here": the caller's own reader (ser_amd/audio_io.py)

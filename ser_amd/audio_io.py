@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import logging
 import struct
+import threading
 import time
 from pathlib import Path
 from typing import NamedTuple
@@ -397,9 +398,59 @@ def read_raw_clip(file_path: str, *, start_seconds: float | None = None,
     return RawClip(view, sample_format, int(channels), max(0, last - first), int(rate))
 
 
+class _DecodedFiles:
+    """The last few files decoded for SEGMENT reads, kept whole: a manifest that cuts one long recording into
+    thousands of utterances (``start_seconds`` / ``duration_seconds`` per utterance, data/manifest.py:175-230) asks for
+    the same file again and again, usually in order.  The reference seeks inside the file (``librosa.load(offset=,
+    duration=)``, audio_utils.py:104-109); decoding the whole file per utterance instead would be quadratic.  Keyed by
+    (path, size, mtime); bounded by bytes; concurrent requests for one file wait for the first decode."""
+
+    def __init__(self, max_bytes: int = 1 << 30, max_files: int = 4) -> None:
+        self.max_bytes, self.max_files = max_bytes, max_files
+        self._lock = threading.Lock()
+        self._done: dict[tuple, tuple] = {}          # key -> (samples, rate), insertion order = age
+        self._pending: dict[tuple, threading.Event] = {}
+
+    def get(self, path: Path):
+        st = path.stat()
+        key = (str(path), st.st_size, st.st_mtime_ns)
+        while True:
+            with self._lock:
+                hit = self._done.pop(key, None)
+                if hit is not None:
+                    self._done[key] = hit              # youngest again
+                    return hit
+                waiter = self._pending.get(key)
+                if waiter is None:
+                    self._pending[key] = threading.Event()
+                    break
+            waiter.wait()
+        try:
+            value = decode_bytes(path.read_bytes())
+            with self._lock:
+                self._done[key] = value
+                total = sum(v[0].nbytes for v in self._done.values())
+                while len(self._done) > 1 and (total > self.max_bytes or len(self._done) > self.max_files):
+                    oldest = next(iter(self._done))
+                    total -= self._done.pop(oldest)[0].nbytes
+            return value
+        finally:
+            with self._lock:
+                self._pending.pop(key).set()
+
+    def clear(self) -> None:
+        with self._lock:
+            self._done.clear()
+
+
+_decoded_files = _DecodedFiles()
+
+
 def decode_file(path: Path, *, start_seconds: float = 0.0, duration_seconds: float | None = None):
     """Decode a file (or a segment of it: frame ``int(start*sr)``, ``int(duration*sr)`` frames)."""
-    samples, rate = decode_bytes(path.read_bytes())
+    if float(start_seconds) == 0.0 and duration_seconds is None:
+        return decode_bytes(path.read_bytes())
+    samples, rate = _decoded_files.get(path)
     first = int(float(start_seconds) * rate)
     if duration_seconds is None:
         return samples[first:], rate

@@ -1507,11 +1507,34 @@ int serhip_read_wav_batch(const char* paths_blob, const int64_t* path_offset, in
         if (dst_offset[i] < 0 || dst_capacity[i] < 0 || dst_offset[i] > dst_bytes - dst_capacity[i])
             return fail(SERHIP_E_INVALID, "serhip_read_wav_batch: region of file " + std::to_string(i) + " lies outside dst");
     unsigned char* slab = static_cast<unsigned char*>(dst);
-    parallel_for(n_files, threads, [&](int64_t i) {
-        serhip_wav_clip c{};
-        c.status = read_one_wav(paths_blob + path_offset[i], start_seconds ? start_seconds[i] : NAN,
-                                duration_seconds ? duration_seconds[i] : NAN, slab, dst_offset[i], dst_capacity[i], &c);
-        clips[i] = c;
+    // runs: consecutive entries that name the same region and the same path share ONE read of the file (segments of
+    // one long recording: a manifest with 1 800 utterances of an hour-long file reads 115 MB once, not 1 800 times)
+    std::vector<int64_t> run_start;
+    run_start.reserve(static_cast<size_t>(n_files) + 1);
+    for (int64_t i = 0; i < n_files; ++i) {
+        const bool shares = i > 0 && dst_offset[i] == dst_offset[i - 1] && dst_capacity[i] == dst_capacity[i - 1] &&
+                            std::strcmp(paths_blob + path_offset[i], paths_blob + path_offset[i - 1]) == 0;
+        if (!shares) run_start.push_back(i);
+    }
+    run_start.push_back(n_files);
+    for (size_t r = 1; r + 1 < run_start.size(); ++r) {   // regions of DIFFERENT runs must not overlap
+        const int64_t a = run_start[r - 1], b = run_start[r];
+        if (dst_capacity[a] > 0 && dst_capacity[b] > 0 && dst_offset[b] < dst_offset[a] + dst_capacity[a] &&
+            dst_offset[a] < dst_offset[b] + dst_capacity[b])
+            return fail(SERHIP_E_INVALID, "serhip_read_wav_batch: regions of files " + std::to_string(a) + " and " +
+                                              std::to_string(b) + " overlap");
+    }
+    parallel_for(static_cast<int64_t>(run_start.size()) - 1, threads, [&](int64_t r) {
+        const int64_t lo = run_start[static_cast<size_t>(r)], hi = run_start[static_cast<size_t>(r) + 1];
+        WaveInSlab wave;
+        const int status = load_wave(paths_blob + path_offset[lo], slab, dst_offset[lo], dst_capacity[lo], &wave);
+        for (int64_t i = lo; i < hi; ++i) {
+            serhip_wav_clip c{};
+            c.status = status != SERHIP_WAV_OK ? status
+                                               : select_clip(wave, start_seconds ? start_seconds[i] : NAN,
+                                                             duration_seconds ? duration_seconds[i] : NAN, &c);
+            clips[i] = c;
+        }
     });
     return SERHIP_OK;
 }

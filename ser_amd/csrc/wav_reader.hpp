@@ -143,9 +143,17 @@ inline int64_t frames_of_seconds(double seconds, int64_t rate) {
     return frames <= 0.0 ? 0 : static_cast<int64_t>(frames);
 }
 
-// One file -> its region [region, region + capacity) of the slab.  Returns the status; fills `clip` on SERHIP_WAV_OK.
-inline int read_one_wav(const char* path, double start_seconds, double duration_seconds, unsigned char* slab,
-                        int64_t region, int64_t capacity, serhip_wav_clip* clip) {
+// What one WAVE file in the slab looks like once its header has been parsed.
+struct WaveInSlab {
+    int64_t body_at = 0;      // byte offset IN THE SLAB of the first frame of the data chunk (a multiple of the sample size)
+    int64_t n_frames = 0;
+    int64_t rate = 0;
+    int channels = 0, block_align = 0, format = 0, sample_size = 0;
+};
+
+// One file -> its region [region, region + capacity) of the slab, header parsed.  Returns the status; fills `wave` on
+// SERHIP_WAV_OK.
+inline int load_wave(const char* path, unsigned char* slab, int64_t region, int64_t capacity, WaveInSlab* wave) {
     static const char kLfs[] = "version https://git-lfs.github.com/spec/v1";
     const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return SERHIP_WAV_IO;
@@ -207,24 +215,41 @@ inline int read_one_wav(const char* path, double start_seconds, double duration_
     }
     if (channels > 64 || rate > 0x7fffffff) return SERHIP_WAV_HOST_DECODE;
     const int64_t n_frames = body_len / block_align;
-    int64_t first = std::isnan(start_seconds) ? 0 : frames_of_seconds(start_seconds, rate);
-    int64_t last = n_frames;
-    if (!std::isnan(duration_seconds)) last = std::min(n_frames, first + frames_of_seconds(duration_seconds, rate));
-    first = std::min(first, n_frames);
-    const int64_t frames = std::max<int64_t>(0, last - first);
-    if (frames == 0) return SERHIP_WAV_EMPTY;
-    int64_t at = region + body_at + first * block_align;
+    int64_t at = region + body_at;
     if (at % ssize != 0) {
-        // chunks are 2-byte aligned, float32 samples want 4: slide the selection down (the header is not needed any more)
+        // chunks are 2-byte aligned, float32 samples want 4: slide the whole payload down (the header in front of it
+        // is not needed any more; every selection from this file then starts on a sample boundary)
         const int64_t aligned = at / ssize * ssize;
-        std::memmove(slab + aligned, slab + at, static_cast<size_t>(frames * block_align));
+        std::memmove(slab + aligned, slab + at, static_cast<size_t>(n_frames * block_align));
         at = aligned;
     }
-    clip->raw_offset = at;
+    wave->body_at = at;
+    wave->n_frames = n_frames;
+    wave->rate = rate;
+    wave->channels = channels;
+    wave->block_align = block_align;
+    wave->format = format;
+    wave->sample_size = ssize;
+    return SERHIP_WAV_OK;
+}
+
+// The frames one job selects from a loaded file (NaN = not given), as the reference's segment reads do:
+// first = (int64)(start * rate), count = (int64)(duration * rate), cut at the end of the file.
+inline int select_clip(const WaveInSlab& wave, double start_seconds, double duration_seconds, serhip_wav_clip* clip) {
+    int64_t first = std::isnan(start_seconds) ? 0 : frames_of_seconds(start_seconds, wave.rate);
+    int64_t last = wave.n_frames;
+    if (!std::isnan(duration_seconds)) {
+        const int64_t count = frames_of_seconds(duration_seconds, wave.rate);
+        last = std::min(wave.n_frames, first > wave.n_frames ? wave.n_frames : first + count);
+    }
+    first = std::min(first, wave.n_frames);
+    const int64_t frames = std::max<int64_t>(0, last - first);
+    if (frames == 0) return SERHIP_WAV_EMPTY;
+    clip->raw_offset = wave.body_at + first * wave.block_align;
     clip->frames = frames;
-    clip->sample_rate = static_cast<int32_t>(rate);
-    clip->channels = channels;
-    clip->sample_format = format;
+    clip->sample_rate = static_cast<int32_t>(wave.rate);
+    clip->channels = wave.channels;
+    clip->sample_format = wave.format;
     return SERHIP_WAV_OK;
 }
 

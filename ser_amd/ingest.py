@@ -184,16 +184,21 @@ def parallel_memcpy(dst_ptr: int, src_ptr: int, nbytes: int, threads: int | None
                                                                 int(nbytes), host_threads(threads)))
 
 
-def plan_slabs(sizes: np.ndarray, slab_bytes: int) -> list[tuple[int, int]]:
+def plan_slabs(sizes: np.ndarray, slab_bytes: int, follows: np.ndarray | None = None) -> list[tuple[int, int]]:
     """Cut ``range(len(sizes))`` into consecutive ``[lo, hi)`` slabs whose 16-byte-aligned file sizes add up to at
     most ``slab_bytes`` (a single larger file gets a slab of its own).  Missing files (-1) take no room: they fail
-    when read."""
+    when read.  ``follows[i]`` marks a job that names the same file as job ``i - 1`` (segments of one recording): it
+    takes no room of its own and is never cut off from the job it follows."""
     room = (np.maximum(sizes, 0) + 15) // 16 * 16
+    if follows is not None:
+        room = np.where(follows, 0, room)
     ends = np.cumsum(room)
     slabs, lo, base, n = [], 0, 0, len(sizes)
     while lo < n:
         hi = int(np.searchsorted(ends, base + slab_bytes, side="right"))
         hi = max(hi, lo + 1)
+        while follows is not None and hi < n and follows[hi]:
+            hi += 1
         slabs.append((lo, hi))
         base = int(ends[hi - 1])
         lo = hi
@@ -323,14 +328,24 @@ def _featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers
     t_b = time.perf_counter()
     sizes = stat_files(None, workers, table=(blob, path_at))
     t_c = time.perf_counter()
-    total = int(np.maximum(sizes, 0).sum())
+    # jobs that name the file of the job before them (segments of one recording, manifest order) share its bytes: the
+    # file is read once, copied once, and every job is a clip descriptor into it (include/serhip.h)
+    follows = None
+    if any_segment and n > 1:
+        follows = np.zeros(n, dtype=bool)
+        follows[1:] = [a == b for a, b in zip(paths[1:], paths)]
+        if not follows.any():
+            follows = None
+    own_room = (np.maximum(sizes, 0) + 15) // 16 * 16               # what a job's file needs
+    room = own_room if follows is None else np.where(follows, 0, own_room)   # what a job adds to its slab
+    head = None if follows is None else np.maximum.accumulate(np.where(follows, 0, np.arange(n)))
+    total = int(room.sum())
     slab_bytes = _env_bytes("SERHIP_SLAB_BYTES", DEFAULT_SLAB_BYTES)
     # ~32 slabs when the corpus is large enough to make pipelining worth it: the first read and the last copy +
     # compute are not overlapped with anything, so they should be a small part of the whole (measured on 550 MB of
     # files: 17 / 34 / 45 / 67 slabs -> 17.5 / 15.0 / 14.9 / 19.1 ms; a slab costs ~0.25 ms of host time to issue)
     slab_bytes = max(min(slab_bytes, max(8 << 20, -(-total // 32))), 1 << 20)
-    slabs = plan_slabs(sizes, slab_bytes)
-    room = (np.maximum(sizes, 0) + 15) // 16 * 16
+    slabs = plan_slabs(sizes, slab_bytes, follows)
     largest = max(int(room[lo:hi].sum()) for lo, hi in slabs)
     stage = _Stage(engine, largest)
     if stats is not None:
@@ -349,7 +364,11 @@ def _featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers
         offs = np.zeros(hi - lo, dtype=np.int64)
         if hi - lo > 1:
             np.cumsum(room[lo:hi - 1], out=offs[1:])
-        clips = read_wav_batch(None, pin.data_ptr(), pin.numel(), offs, room[lo:hi], table=(blob, path_at[lo:hi]),
+        used = int(offs[-1] + room[hi - 1]) if hi > lo else 0
+        capacity = room[lo:hi]
+        if head is not None:                        # a follower names its head's region
+            offs, capacity = offs[head[lo:hi] - lo], own_room[head[lo:hi]]
+        clips = read_wav_batch(None, pin.data_ptr(), pin.numel(), offs, capacity, table=(blob, path_at[lo:hi]),
                                start_seconds=job_starts[lo:hi] if any_segment else None,
                                duration_seconds=job_durations[lo:hi] if any_segment else None, threads=workers)
         t2 = time.perf_counter()
@@ -366,7 +385,7 @@ def _featurize_jobs_pipelined(jobs, *, feature_flags, audio_read_config, workers
         clock["reader_wait_pinned_s"] += t1 - t0
         clock["reader_native_s"] += t2 - t1
         clock["reader_fallback_s"] += time.perf_counter() - t2
-        return clips, int(offs[-1] + room[hi - 1]) if hi > lo else 0, fallback
+        return clips, used, fallback
 
     def _run_slabs():
         with ThreadPoolExecutor(max_workers=1, thread_name_prefix="serhip-reader") as reader:

@@ -410,3 +410,176 @@ def test_interpreter_settings_are_restored_by_the_last_concurrent_call():
         assert not gc.isenabled()
     finally:
         gc.enable()
+
+
+def test_segments_of_one_recording_share_one_read(tmp_path, native_lib):
+    """Consecutive jobs that name the same file and the same region (``serhip_read_wav_batch``): the file is read
+    once and every job selects its own frames -- the selections equal the Python reader's, for PCM16 stereo and
+    for a float32 payload that sits on a 2-byte boundary (the whole payload is slid to a sample boundary once)."""
+    from ser_amd import ingest
+    from ser_amd.audio_io import read_raw_clip
+
+    rng = np.random.default_rng(41)
+    a = tmp_path / "long16.wav"
+    a.write_bytes(_wav_bytes(1, 16, 2, 16000, rng.integers(-30000, 30000, (16000 * 4, 2), dtype=np.int16).astype("<i2").tobytes()))
+    b = tmp_path / "long32.wav"
+    b.write_bytes(_wav_bytes(3, 32, 1, 22050, rng.standard_normal(22050 * 3).astype("<f4").tobytes(), junk=b"sixsix"))
+    c = tmp_path / "other.wav"
+    c.write_bytes(_wav_bytes(1, 16, 1, 16000, rng.integers(-30000, 30000, 8000, dtype=np.int16).astype("<i2").tobytes()))
+    segs = [(0.0, 1.0), (0.5, 0.25), (1.0, None), (3.9, 5.0), (None, 2.0), (7.0, 1.0), (2.0, 1e-9)]   # the last two select nothing
+    jobs = [(str(a), s, d) for s, d in segs] + [(str(c), None, None)] + [(str(b), s, d) for s, d in segs] + [(str(a), 0.25, 0.5)]
+    paths = [j[0] for j in jobs]
+    sizes = ingest.stat_files(paths, 4)
+    follows = np.zeros(len(jobs), dtype=bool)
+    follows[1:] = [x == y for x, y in zip(paths[1:], paths)]
+    assert follows.sum() == 2 * (len(segs) - 1)
+    # the planner never cuts a run, whatever the budget
+    for budget in (1 << 20, 1 << 12, 1 << 30):
+        slabs = ingest.plan_slabs(sizes, budget, follows)
+        assert slabs[0][0] == 0 and slabs[-1][1] == len(jobs) and all(x[1] == y[0] for x, y in zip(slabs, slabs[1:]))
+        assert not any(follows[lo] for lo, _ in slabs)
+    own = (sizes + 15) // 16 * 16
+    room = np.where(follows, 0, own)
+    head = np.maximum.accumulate(np.where(follows, 0, np.arange(len(jobs))))
+    starts = np.concatenate(([0], np.cumsum(room)[:-1]))
+    buf = np.zeros(int(room.sum()) + 64, dtype=np.uint8)
+    clips = ingest.read_wav_batch(paths, buf.ctypes.data, buf.size, starts[head], own[head],
+                                  start_seconds=[j[1] for j in jobs], duration_seconds=[j[2] for j in jobs], threads=4)
+    for (path, s, d), clip in zip(jobs, clips):
+        want = read_raw_clip(path, start_seconds=s, duration_seconds=d)
+        if want.frames == 0:
+            assert clip["status"] == 6, (path, s, d)          # SERHIP_WAV_EMPTY
+            continue
+        assert clip["status"] == 0 and clip["frames"] == want.frames and clip["channels"] == want.channels
+        width = (2 if want.sample_format == "s16" else 4) * want.channels
+        assert clip["raw_offset"] % (width // want.channels) == 0
+        got = buf[clip["raw_offset"] : clip["raw_offset"] + want.frames * width].tobytes()
+        assert got == bytes(want.payload), (path, s, d)
+    # regions of different files must not overlap
+    with pytest.raises(Exception, match="overlap"):
+        ingest.read_wav_batch([str(a), str(c)], buf.ctypes.data, buf.size, np.asarray([0, 16]), own[[0, 7]], threads=2)
+
+
+def test_segment_reads_decode_a_file_once(tmp_path, monkeypatch):
+    """The Python reader keeps the last few files it decoded for segment reads (``audio_io._decoded_files``): N
+    utterances of one recording cost one decode, also when a team of threads asks at once; a changed file is decoded
+    again; whole-file reads do not go through the cache."""
+    import threading
+    import time
+    import wave
+
+    from ser_amd import audio_io
+
+    rng = np.random.default_rng(43)
+    p = tmp_path / "rec24.wav"                               # 24-bit: the host decoder's business
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(3)
+        w.setframerate(8000)
+        w.writeframes(rng.integers(0, 255, 3 * 8000 * 6, dtype=np.uint8).tobytes())
+    calls = []
+    real = audio_io.decode_bytes
+
+    def counting(data):
+        calls.append(len(data))
+        time.sleep(0.05)
+        return real(data)
+
+    monkeypatch.setattr(audio_io, "decode_bytes", counting)
+    audio_io._decoded_files.clear()
+    whole, rate = audio_io.read_audio_file(str(p))
+    assert len(calls) == 1 and rate == 8000
+    out = [None] * 12
+
+    def ask(k):
+        out[k] = audio_io.read_audio_file(str(p), start_seconds=0.25 * k, duration_seconds=0.5)[0]
+
+    threads = [threading.Thread(target=ask, args=(k,)) for k in range(12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert len(calls) == 2                                   # one more decode for all twelve segments
+    raw, _ = real(p.read_bytes())
+    for k in range(12):
+        seg = raw[int(0.25 * k * 8000) : int(0.25 * k * 8000) + 4000]
+        np.testing.assert_array_equal(out[k], audio_io.prepare_audio_buffer(seg))
+    audio_io.read_audio_file(str(p), start_seconds=1.0, duration_seconds=1.0)
+    assert len(calls) == 2
+    time.sleep(0.01)
+    with wave.open(str(p), "wb") as w:                       # the file changes: size / mtime differ
+        w.setnchannels(1)
+        w.setsampwidth(3)
+        w.setframerate(8000)
+        w.writeframes(rng.integers(0, 255, 3 * 8000 * 5, dtype=np.uint8).tobytes())
+    audio_io.read_audio_file(str(p), start_seconds=1.0, duration_seconds=1.0)
+    assert len(calls) == 3
+    audio_io._decoded_files.clear()
+
+
+@pytest.mark.gpu
+def test_manifest_segments_of_long_recordings(tmp_path, monkeypatch):
+    """Utterances cut from long recordings by ``start_seconds`` / ``duration_seconds`` (the reference's manifests,
+    data/manifest.py:175-230; read with ``librosa.load(offset=, duration=)``, audio_utils.py:104-109): the pipelined
+    loader reads each recording once per slab and features every utterance from descriptors into it; rows equal the
+    sequential loader's, for a PCM16 WAVE (device path) and a FLAC (host-decode lane with its decoded-file cache)."""
+    import wave
+
+    import torch
+
+    from flac_writer import encode_stream
+    from ser_amd import AudioReadConfig, FeatureFlags, audio_io
+    from ser_amd.data_loader import featurize_audio_jobs_device
+
+    rng = np.random.default_rng(47)
+    n = 16000 * 40
+    t = np.arange(n)[:, None]
+    pcm = np.rint(6000 * np.sin(2 * np.pi * (180 + 3e-4 * t) * t / 16000 * np.asarray([1.0, 1.5])) + rng.integers(-400, 400, (n, 2))).astype(np.int64)
+    with wave.open(str(tmp_path / "long.wav"), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.astype("<i2").tobytes())
+    m = 16000 * 12
+    mono = pcm[:m, :1]
+    frames = [{"block": 4096, "subframes": [{"type": "fixed", "order": 2, "partition_order": 4}]}] * (m // 4096)
+    frames = frames + [{"block": m % 4096, "subframes": [{"type": "fixed", "order": 1}]}] if m % 4096 else frames
+    (tmp_path / "long.flac").write_bytes(encode_stream(mono, bits=16, rate=16000, frames=frames))
+    with wave.open(str(tmp_path / "short.wav"), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(mono[:20000].astype("<i2").tobytes())
+    jobs = [(str(tmp_path / "short.wav"), None, None)]
+    jobs += [(str(tmp_path / "long.wav"), 1.4 * k, 1.5) for k in range(27)]
+    jobs += [(str(tmp_path / "long.wav"), 39.5, 3.0), (str(tmp_path / "long.wav"), 41.0, 1.0)]    # cut at the end; past the end
+    jobs += [(str(tmp_path / "short.wav"), 0.25, None)]
+    jobs += [(str(tmp_path / "long.flac"), 1.1 * k, 1.25) for k in range(9)]
+    jobs += [(str(tmp_path / "long.wav"), 0.0, 2.0)]
+    flags = FeatureFlags(tonnetz=False)
+    cfg = AudioReadConfig(max_retries=1, retry_delay_seconds=0.0)
+    audio_io._decoded_files.clear()
+    seq, seq_err = featurize_audio_jobs_device(jobs, feature_flags=flags, audio_read_config=cfg, workers=4, pipelined=False)
+    for slab_bytes in (1 << 20, 64 << 20):
+        monkeypatch.setenv("SERHIP_SLAB_BYTES", str(slab_bytes))
+        stats = {}
+        pip, pip_err = featurize_audio_jobs_device(jobs, feature_flags=flags, audio_read_config=cfg, workers=4, pipelined=True, stats=stats)
+        torch.cuda.synchronize()
+        # the 2.56 MB recording is counted once per run of its jobs, not once per utterance
+        assert stats["file_bytes"] < 3 * (tmp_path / "long.wav").stat().st_size
+        a, b = seq.cpu().numpy(), pip.cpu().numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        np.testing.assert_array_equal(np.nan_to_num(a), np.nan_to_num(b))
+        for e_seq, e_pip in zip(seq_err, pip_err):
+            assert type(e_seq) is type(e_pip)
+    failed = [i for i, e in enumerate(pip_err) if e is not None]
+    assert failed == [29]                                   # the segment that starts past the end: "contains no samples"
+    assert np.isfinite(b[[i for i in range(len(jobs)) if i != 29]]).all()
+    # segment k of the WAVE equals the same samples handed over as a host clip (prepared like a file read)
+    raw = (pcm[int(1.4 * 3 * 16000) : int(1.4 * 3 * 16000) + 24000].astype(np.float32) / np.float32(32768.0))
+    clip = audio_io.prepare_audio_buffer(audio_io.mix_down_like_librosa_load(raw))
+    from ser_amd.engine import get_engine
+
+    want = get_engine().features(clip, [0], [len(clip)], 16000, flags).cpu().numpy()[0]
+    np.testing.assert_array_equal(b[1 + 3], want)
+    audio_io._decoded_files.clear()
