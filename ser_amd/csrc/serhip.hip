@@ -1524,10 +1524,13 @@ int serhip_read_wav_batch(const char* paths_blob, const int64_t* path_offset, in
             return fail(SERHIP_E_INVALID, "serhip_read_wav_batch: regions of files " + std::to_string(a) + " and " +
                                               std::to_string(b) + " overlap");
     }
-    parallel_for(static_cast<int64_t>(run_start.size()) - 1, threads, [&](int64_t r) {
+    const int64_t n_runs = static_cast<int64_t>(run_start.size()) - 1;
+    // threads left over when the batch holds fewer files than the team has members read pieces of the large ones
+    const int read_threads = static_cast<int>(std::max<int64_t>(1, threads / std::max<int64_t>(1, n_runs)));
+    parallel_for(n_runs, threads, [&](int64_t r) {
         const int64_t lo = run_start[static_cast<size_t>(r)], hi = run_start[static_cast<size_t>(r) + 1];
         WaveInSlab wave;
-        const int status = load_wave(paths_blob + path_offset[lo], slab, dst_offset[lo], dst_capacity[lo], &wave);
+        const int status = load_wave(paths_blob + path_offset[lo], slab, dst_offset[lo], dst_capacity[lo], &wave, read_threads);
         for (int64_t i = lo; i < hi; ++i) {
             serhip_wav_clip c{};
             c.status = status != SERHIP_WAV_OK ? status

@@ -153,7 +153,8 @@ struct WaveInSlab {
 
 // One file -> its region [region, region + capacity) of the slab, header parsed.  Returns the status; fills `wave` on
 // SERHIP_WAV_OK.
-inline int load_wave(const char* path, unsigned char* slab, int64_t region, int64_t capacity, WaveInSlab* wave) {
+inline int load_wave(const char* path, unsigned char* slab, int64_t region, int64_t capacity, WaveInSlab* wave,
+                     int read_threads = 1) {
     static const char kLfs[] = "version https://git-lfs.github.com/spec/v1";
     const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return SERHIP_WAV_IO;
@@ -168,14 +169,41 @@ inline int load_wave(const char* path, unsigned char* slab, int64_t region, int6
     }
     unsigned char* data = slab + region;
     int64_t got = 0;
-    while (got < st.st_size) {
-        const ssize_t r = ::read(fd, data + got, static_cast<size_t>(st.st_size - got));
-        if (r < 0) {
+    constexpr int64_t kPiece = 8 << 20;
+    if (read_threads > 1 && st.st_size >= 4 * kPiece) {
+        // a long recording in a batch of few files: its pieces are read by several threads (pread), not by one
+        const int64_t pieces = (st.st_size + kPiece - 1) / kPiece;
+        std::atomic<bool> failed{false};
+        std::atomic<int64_t> total{0};
+        parallel_for(pieces, read_threads, [&](int64_t p) {
+            int64_t at = p * kPiece;
+            const int64_t end = std::min<int64_t>(st.st_size, at + kPiece);
+            while (at < end) {
+                const ssize_t r = ::pread(fd, data + at, static_cast<size_t>(end - at), static_cast<off_t>(at));
+                if (r < 0) {
+                    failed.store(true);
+                    return;
+                }
+                if (r == 0) return;   // the file shrank: what was read is what there is
+                at += r;
+                total.fetch_add(r);
+            }
+        });
+        if (failed.load()) {
             ::close(fd);
             return SERHIP_WAV_IO;
         }
-        if (r == 0) break;
-        got += r;
+        got = total.load();           // (short only if the file shrank under the reader: the chunk walk below cuts there)
+    } else {
+        while (got < st.st_size) {
+            const ssize_t r = ::read(fd, data + got, static_cast<size_t>(st.st_size - got));
+            if (r < 0) {
+                ::close(fd);
+                return SERHIP_WAV_IO;
+            }
+            if (r == 0) break;
+            got += r;
+        }
     }
     ::close(fd);
     const int64_t len = got;

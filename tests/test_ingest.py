@@ -583,3 +583,33 @@ def test_manifest_segments_of_long_recordings(tmp_path, monkeypatch):
     want = get_engine().features(clip, [0], [len(clip)], 16000, flags).cpu().numpy()[0]
     np.testing.assert_array_equal(b[1 + 3], want)
     audio_io._decoded_files.clear()
+
+
+def test_long_recording_is_read_in_pieces_by_several_threads(tmp_path, native_lib):
+    """A file of 32 MiB or more in a batch with fewer files than threads is read with ``pread`` in 8 MiB pieces by
+    the spare threads: same bytes as one sequential read, alone in the batch and beside a second file."""
+    from ser_amd import ingest
+
+    rng = np.random.default_rng(53)
+    payload = rng.integers(-32768, 32767, 9 * (1 << 20) * 2 + 12345, dtype=np.int16).astype("<i2").tobytes()     # ~36 MiB
+    big = tmp_path / "big.wav"
+    big.write_bytes(_wav_bytes(1, 16, 1, 16000, payload))
+    small = tmp_path / "small.wav"
+    small.write_bytes(_wav_bytes(1, 16, 1, 16000, payload[:50000]))
+    for paths in ([str(big)], [str(small), str(big)], [str(big), str(big)]):
+        sizes = ingest.stat_files(paths, 4)
+        own = (sizes + 15) // 16 * 16
+        starts = np.concatenate(([0], np.cumsum(own)[:-1]))
+        if paths[0] == paths[-1] and len(paths) == 2:      # two utterances of the big file: one shared region
+            starts, own = np.asarray([0, 0]), np.asarray([own[0], own[0]])
+        buf = np.zeros(int(own.sum()) + 64, dtype=np.uint8)
+        clips = ingest.read_wav_batch(paths, buf.ctypes.data, buf.size, starts, own, threads=8,
+                                      start_seconds=[None, 100.0][: len(paths)] if len(paths) == 2 else None,
+                                      duration_seconds=[None, 2.0][: len(paths)] if len(paths) == 2 else None)
+        assert not clips["status"].any()
+        for path, clip in zip(paths, clips):
+            want = payload if path == str(big) else payload[:50000]
+            if clip["frames"] == 32000:                     # the (100 s, 2 s) utterance
+                want = want[2 * 1600000 : 2 * 1632000]
+            got = buf[clip["raw_offset"] : clip["raw_offset"] + 2 * clip["frames"]].tobytes()
+            assert len(got) == len(want) and got == want, path
