@@ -49,6 +49,25 @@ def _resolve(settings) -> FeatureSettings:
     return FeatureSettings(feature_flags=coerce_feature_flags(settings.feature_flags), audio_read=audio_read)
 
 
+def _long_file_on_device(file: str):
+    """``(audio device tensor, sample_rate)`` for a long PCM16 / float32 WAVE file read and prepared without a host
+    pass over its samples (``ingest.prepared_file_on_device``), else None: short files, every other encoding and
+    every failure take ``read_audio_file``, whose results, retries and errors are the reference's
+    (``SERHIP_INGEST=sequential`` switches the shortcut off)."""
+    import os
+
+    from . import ingest
+
+    try:
+        if os.environ.get("SERHIP_INGEST", "pipelined") == "sequential" or os.path.getsize(file) < ingest.DEVICE_PREPARE_FILE_BYTES:
+            return None
+        from .engine import get_engine
+
+        return ingest.prepared_file_on_device(get_engine(), str(file))
+    except OSError:
+        return None
+
+
 def extract_feature_from_signal(audio: NDArray[np.float32], sample_rate: int, *, settings=None) -> FeatureVector:
     """Settings-flavoured wrapper around :func:`ser_amd.dsp.extract_feature_from_signal`."""
     return dsp.extract_feature_from_signal(audio, sample_rate, feature_flags=_resolve(settings).feature_flags)
@@ -73,11 +92,15 @@ def extract_feature_frames(audiofile: str, frame_size: int = 3, frame_stride: in
     if frame_stride <= 0:
         raise ValueError("frame_stride must be greater than zero.")
     active = _resolve(settings)
-    audio, sample_rate = read_audio_file(audiofile, audio_read_config=active.audio_read)
     backend = HandcraftedBackend(
         frame_size_seconds=frame_size, frame_stride_seconds=frame_stride, feature_flags=active.feature_flags
     )
-    encoded = backend.encode_sequence(audio=audio, sample_rate=sample_rate)
+    on_device = _long_file_on_device(audiofile)
+    if on_device is not None:
+        encoded = backend.encode_sequence_device(*on_device)
+    else:
+        audio, sample_rate = read_audio_file(audiofile, audio_read_config=active.audio_read)
+        encoded = backend.encode_sequence(audio=audio, sample_rate=sample_rate)
     return [
         FeatureFrame(
             start_seconds=float(encoded.frame_start_seconds[i]),

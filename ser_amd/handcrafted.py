@@ -86,6 +86,34 @@ class HandcraftedBackend:
             raise ValueError("audio must contain at least one sample.")
         return self.encode_sequences([audio], sample_rate)[0]
 
+    def encode_sequence_device(self, audio_dev, sample_rate: int) -> EncodedSequence:
+        """:meth:`encode_sequence` for a recording that already sits on the GPU as prepared float32 samples
+        (``ingest.prepared_file_on_device``: finite by construction -- the device prepare scrubs): the sliding
+        windows are descriptors into it."""
+        if sample_rate <= 0:
+            raise ValueError("sample_rate must be a positive integer.")
+        if audio_dev.dim() != 1:
+            raise ValueError("audio must be mono (1D array).")
+        n = int(audio_dev.numel())
+        if n == 0:
+            raise ValueError("audio must contain at least one sample.")
+        require_accelerated(self._feature_flags)
+        dsp.check_flags_for_rate(self._feature_flags, sample_rate)
+        starts, ends = sliding_window_bounds(n, sample_rate, self._frame_size_seconds, self._frame_stride_seconds)
+        if starts.size == 0:
+            raise ValueError("Could not extract handcrafted features from provided audio.")
+        if self._feature_flags.width():
+            emb = get_engine(audio_dev.device.index).features(audio_dev, starts, ends - starts, sample_rate,
+                                                              self._feature_flags).cpu().numpy()
+        else:
+            emb = np.empty((starts.size, 0), dtype=np.float32)
+        return EncodedSequence(
+            embeddings=np.ascontiguousarray(emb, dtype=np.float32),
+            frame_start_seconds=starts.astype(np.float64) / float(sample_rate),
+            frame_end_seconds=ends.astype(np.float64) / float(sample_rate),
+            backend_id=self.backend_id,
+        )
+
     def extract_vector(self, audio: NDArray[np.float32], sample_rate: int) -> FeatureVector:
         """One feature vector for the whole signal (training path)."""
         return np.asarray(

@@ -613,3 +613,49 @@ def test_long_recording_is_read_in_pieces_by_several_threads(tmp_path, native_li
                 want = want[2 * 1600000 : 2 * 1632000]
             got = buf[clip["raw_offset"] : clip["raw_offset"] + 2 * clip["frames"]].tobytes()
             assert len(got) == len(want) and got == want, path
+
+
+@pytest.mark.gpu
+def test_long_file_inference_prepares_on_the_device(tmp_path, monkeypatch):
+    """``extract_feature_frames`` on a recording of 4 MiB or more reads it with the reader team and prepares it on the
+    GPU (``ingest.prepared_file_on_device``); frames, timestamps and features equal the host-prepared path's bit for
+    bit (stereo PCM16 and misaligned float32), and a file the native reader does not take falls back unnoticed."""
+    import wave
+
+    from ser_amd import FeatureFlags, extract_feature_frames, ingest
+    from ser_amd.feature_extractor import FeatureSettings
+
+    rng = np.random.default_rng(59)
+    n = 16000 * 80
+    t = np.arange(n)[:, None]
+    pcm = np.rint(5000 * np.sin(2 * np.pi * (140 + 2e-4 * t) * t / 16000 * np.asarray([1.0, 1.25])) + rng.integers(-300, 300, (n, 2))).astype("<i2")
+    with wave.open(str(tmp_path / "talk.wav"), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+    f32 = (pcm[:, 0].astype(np.float32) / 20000.0)
+    f32[1000] = np.nan
+    (tmp_path / "talk32.wav").write_bytes(_wav_bytes(3, 32, 1, 16000, f32.astype("<f4").tobytes(), junk=b"sixsix"))
+    with wave.open(str(tmp_path / "talk24.wav"), "wb") as w:       # 24-bit: host decode, whatever its size
+        w.setnchannels(1)
+        w.setsampwidth(3)
+        w.setframerate(16000)
+        w.writeframes(rng.integers(0, 255, 3 * 16000 * 100, dtype=np.uint8).tobytes())
+    settings = FeatureSettings(feature_flags=FeatureFlags(tonnetz=False))
+    calls = []
+    real = ingest.prepared_file_on_device
+    monkeypatch.setattr(ingest, "prepared_file_on_device", lambda *a, **k: (calls.append(a[1]), real(*a, **k))[1])
+    for name, expect_device in (("talk.wav", True), ("talk32.wav", True), ("talk24.wav", False)):
+        calls.clear()
+        monkeypatch.delenv("SERHIP_INGEST", raising=False)
+        fast = extract_feature_frames(str(tmp_path / name), settings=settings)
+        assert len(calls) == 1
+        monkeypatch.setenv("SERHIP_INGEST", "sequential")
+        slow = extract_feature_frames(str(tmp_path / name), settings=settings)
+        assert len(calls) == 1                                     # the host path did not ask
+        assert len(fast) == len(slow) >= 80
+        for a, b in zip(fast, slow):
+            assert (a.start_seconds, a.end_seconds) == (b.start_seconds, b.end_seconds)
+            np.testing.assert_array_equal(a.features, b.features)
+        assert (real(__import__("ser_amd.engine", fromlist=["get_engine"]).get_engine(), str(tmp_path / name)) is not None) == expect_device
