@@ -76,6 +76,17 @@ def extract_feature_from_signal(audio: NDArray[np.float32], sample_rate: int, *,
 def extract_feature(file: str, *, settings=None) -> FeatureVector:
     """One feature vector for a whole audio file."""
     active = _resolve(settings)
+    on_device = _long_file_on_device(file)
+    if on_device is not None:
+        from .engine import get_engine
+        from .types import require_accelerated
+
+        audio_dev, sample_rate = on_device
+        require_accelerated(active.feature_flags)
+        dsp.check_flags_for_rate(active.feature_flags, sample_rate)
+        row = get_engine(audio_dev.device.index).features(audio_dev, [0], [int(audio_dev.numel())], sample_rate,
+                                                         active.feature_flags)
+        return np.asarray(row.cpu().numpy()[0], dtype=np.float64)
     try:
         audio, sample_rate = read_audio_file(file, audio_read_config=active.audio_read)
     except Exception as err:

@@ -659,3 +659,11 @@ def test_long_file_inference_prepares_on_the_device(tmp_path, monkeypatch):
             assert (a.start_seconds, a.end_seconds) == (b.start_seconds, b.end_seconds)
             np.testing.assert_array_equal(a.features, b.features)
         assert (real(__import__("ser_amd.engine", fromlist=["get_engine"]).get_engine(), str(tmp_path / name)) is not None) == expect_device
+        from ser_amd import extract_feature
+
+        monkeypatch.delenv("SERHIP_INGEST", raising=False)
+        whole_fast = extract_feature(str(tmp_path / name), settings=settings)
+        monkeypatch.setenv("SERHIP_INGEST", "sequential")
+        whole_slow = extract_feature(str(tmp_path / name), settings=settings)
+        assert whole_fast.dtype == np.float64 and whole_fast.shape == (187,)
+        np.testing.assert_array_equal(whole_fast, whole_slow)
