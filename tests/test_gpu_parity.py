@@ -82,6 +82,13 @@ def test_plain_c_host_over_the_c_abi(engine, flags, tmp_path):
     from ser_amd.data_loader import featurize_audio_jobs_device
 
     exe = Path(__file__).resolve().parent.parent / "examples" / "host_c_abi"
+    if not exe.exists():      # a tree that was copied without its built artefacts: build() compiles it (gcc, a second)
+        import sys
+
+        sys.path.insert(0, str(exe.parent.parent))
+        import __graft_entry__
+
+        __graft_entry__.build()
     assert exe.exists(), "examples/host_c_abi is built by __graft_entry__.build()"
     rng = np.random.default_rng(31)
     paths = []
