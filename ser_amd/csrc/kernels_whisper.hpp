@@ -18,7 +18,7 @@ constexpr int kWNfft = 400;
 constexpr int kWHop = 160;
 constexpr int kWBins = 201;
 constexpr int kWHalf = 200;          // packed complex points per frame
-constexpr int kWWaves = 12;          // waves per workgroup (3 per SIMD; ~150 KB of LDS, one workgroup per CU)
+constexpr int kWWaves = 16;          // waves per workgroup (4 per SIMD; ~128 KB of LDS, one workgroup per CU)
 constexpr int kWTile = 96;           // frames per workgroup
 constexpr int kWMelWCap = 1024;      // sparse mel taps (80 mels: ~400, 128 mels: ~500)
 
@@ -64,8 +64,7 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
     __shared__ v2d s_tw400[kWBins + 1];
     __shared__ double s_win[kWNfft];
     __shared__ float s_melw[kWMelWCap];
-    __shared__ v2d s_z[kWWaves][kWHalf];
-    __shared__ v2d s_y[kWWaves][kWHalf];
+    __shared__ v2d s_z[kWWaves][kWHalf];   // ONE buffer per wave: every stage below works in place (see the stages)
     __shared__ float s_p[kWWaves][kWBins + 3];
     __shared__ float s_tile[128][kWTile + 1];
     __shared__ float s_red[kWWaves];
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
     const int4 rng0 = wt.mel_rng[lane];
     const int4 rng1 = wt.mel_rng[64 + lane];
     v2d* z = s_z[wave];
-    v2d* y = s_y[wave];
+    v2d* y = z;   // stage 1a rewrites exactly the slots it read; 1b and 2 rely on a wave's LDS accesses completing in order
     float* p = s_p[wave];
     float vmax = -INFINITY;
 
