@@ -951,6 +951,11 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
     const int off_mel = off_chroma + (want_chroma ? kChroma : 0);
     const int off_contrast = off_mel + (want_mel ? kMels : 0);
     const int nbins = 1 + sd.n_fft / 2;
+    if constexpr (kMode == 1) {
+        // k_tuning_waves ran first and took every segment whose peaks fit one wave's staging: what it left
+        // (index -1: more than kTwPeakCap peaks or kTwFrameCap frames) is this kernel's
+        if (want_chroma && sc.tuning_idx[blockIdx.x] >= 0) return;
+    }
 
     // ---- mel mean and MFCC (power_to_db, top_db=80 vs the segment max, DCT of the time mean)
     if (kMode != 1 && (want_mfcc || want_mel)) {
@@ -1284,6 +1289,177 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         orow[off_chroma + tid] = s / static_cast<float>(sd.n_stft);
     }
     }  // kMode == 0
+}
+
+// ---------------------------------------------------------------------------------------
+// k_tuning_waves: the tuning estimate of k_segment_finish<1> with ONE WAVE per segment (four segments per
+// workgroup) for the common case -- at most kTwPeakCap peaks in at most kTwFrameCap frames.  A wave needs no
+// workgroup barrier: its LDS staging is its own, counts are prefix-summed with wave scans, the median is found
+// by a 32-step bitwise search whose counts are ballots (one v_cmp + one s_bcnt1 per 64 keys), the histogram is
+// the same 100-bin LDS histogram.  Same discrete decisions as k_segment_finish<1> (order statistics and counts
+// do not depend on the order of the keys), so the same tuning index.  Writes sc.tuning_idx[seg] (or -1: left
+// to k_segment_finish<1>, which runs next and skips the segments done here), sc.seg_cmax[seg], tuning_out.
+// ---------------------------------------------------------------------------------------
+constexpr int kTwWaves = 4;
+constexpr int kTwPeakCap = 1024;
+constexpr int kTwFrameCap = 1024;
+constexpr int kTwKeysPerLane = kTwPeakCap / 64;
+
+struct TuningWaveShared {
+    double edges[kTunings];
+    unsigned keys[kTwWaves][kTwPeakCap];
+    float pitch[kTwWaves][kTwPeakCap];
+    unsigned hist[kTwWaves][128];
+    int cnt[kTwWaves][64];
+    int off[kTwWaves][64];
+};
+
+__global__ __launch_bounds__(kTwWaves * 64) void k_tuning_waves(const SegDesc* __restrict__ segs, int n_seg, PlanTables tb,
+                                                                Scratch sc, float* __restrict__ tuning_out) {
+    __shared__ TuningWaveShared sh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < kTunings; i += kTwWaves * 64) sh.edges[i] = tb.edges[i];
+    __syncthreads();                       // the only workgroup barrier: everything below is per wave
+    const int seg = blockIdx.x * kTwWaves + wave;
+    if (seg >= n_seg) return;
+    const SegDesc sd = segs[seg];
+    const size_t base = static_cast<size_t>(sd.stft_base);
+    if (sd.n_stft > kTwFrameCap) {
+        if (lane == 0) sc.tuning_idx[seg] = -1;
+        return;
+    }
+    // ---- counts of all frames: total and the segment's frame-max key
+    int total = 0;
+    unsigned frame_max = 0;
+    for (int t = lane; t < sd.n_stft; t += 64) {
+        const unsigned word = static_cast<unsigned>(sc.peak_cnt[base + t]);
+        total += static_cast<int>(word & kPeakCountMask);
+        frame_max = max(frame_max, word & ~kPeakCountMask);
+    }
+    total = wave_sum_int(total);
+    if (total > kTwPeakCap) {
+        if (lane == 0) sc.tuning_idx[seg] = -1;
+        return;
+    }
+    frame_max = wave_max_bits(frame_max);
+    if (lane == 0) sc.seg_cmax[seg] = frame_max;
+    const int n = total;
+    int tuning_idx = 50;   // edge 50 is exactly 0.0: librosa's answer for an empty peak set
+    if (n > 0) {
+        unsigned* keys = sh.keys[wave];
+        float* pitch = sh.pitch[wave];
+        // ---- gather: 64 frames per round (lane = frame for the scan), then 16 lanes per frame
+        int placed = 0;
+        for (int t0 = 0; t0 < sd.n_stft; t0 += 64) {
+            const int t = t0 + lane;
+            const int c = t < sd.n_stft ? static_cast<int>(static_cast<unsigned>(sc.peak_cnt[base + t]) & kPeakCountMask) : 0;
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            sh.cnt[wave][lane] = c;
+            sh.off[wave][lane] = placed + incl - c;
+            wave_lds_sync();
+            const int in_round = min(64, sd.n_stft - t0);
+            const int g = lane >> 4, l16 = lane & 15;
+            // eight frames in flight per 16-lane group, all loads independent (a frame-by-frame walk is a chain of
+            // dependent global round trips: 143 us per 12 500 segments against 9x us this way)
+            for (int f0 = g; f0 < in_round; f0 += 32) {
+                v2f val[8];
+                int dst[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int f = f0 + 4 * u;
+                    dst[u] = -1;
+                    if (f < in_round && l16 < sh.cnt[wave][f]) {
+                        val[u] = sc.peaks[(base + t0 + f) * sc.peak_cap + l16];
+                        dst[u] = sh.off[wave][f] + l16;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (dst[u] >= 0) {
+                        keys[dst[u]] = float_key(val[u].y);
+                        pitch[dst[u]] = val[u].x;
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {   // frames with more than 16 peaks
+                    const int f = f0 + 4 * u;
+                    if (f < in_round) {
+                        const int cf = sh.cnt[wave][f], of = sh.off[wave][f];
+                        const v2f* row = sc.peaks + (base + t0 + f) * sc.peak_cap;
+                        for (int j = l16 + 16; j < cf; j += 16) {
+                            const v2f pm = row[j];
+                            keys[of + j] = float_key(pm.y);
+                            pitch[of + j] = pm.x;
+                        }
+                    }
+                }
+            }
+            placed += __builtin_amdgcn_readlane(incl, 63);
+            wave_lds_sync();               // cnt / off are rewritten by the next round
+        }
+        // ---- my keys (lane owns slots lane, lane + 64, ...); slots past n hold a key no threshold exceeds
+        const int per_lane = (n + 63) >> 6;
+        unsigned k[kTwKeysPerLane];
+#pragma unroll
+        for (int i = 0; i < kTwKeysPerLane; ++i) {
+            const int idx = lane + 64 * i;
+            k[i] = (i < per_lane && idx < n) ? keys[idx] : 0xFFFFFFFFu;
+        }
+        auto count_below = [&](unsigned t) {
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < kTwKeysPerLane; ++i)
+                if (i < per_lane) c += __builtin_popcountll(__ballot(k[i] < t));
+            return c;
+        };
+        // ---- sorted[n / 2]: the largest v with at most n / 2 keys strictly below it, built bit by bit
+        const int kth = n >> 1;
+        unsigned v = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned t = v | (1u << bit);
+            if (count_below(t) <= kth) v = t;
+        }
+        float thr = key_float(v);
+        if ((n & 1) == 0) {
+            // the element of rank n/2 - 1: the largest key below v if exactly n/2 keys are below it, else v (a tie)
+            unsigned below = 0;
+#pragma unroll
+            for (int i = 0; i < kTwKeysPerLane; ++i)
+                if (i < per_lane && k[i] < v) below = max(below, k[i]);
+            below = wave_max_bits(below);
+            const float lo = (count_below(v) == kth) ? key_float(below) : thr;
+            thr = (lo + thr) / 2.0f;       // np.median of an even count: f32 mean of the middle pair
+        }
+        // ---- histogram of the residuals of the peaks at or above the median
+        unsigned* hist = sh.hist[wave];
+        hist[lane] = 0;
+        hist[lane + 64] = 0;
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < kTwKeysPerLane; ++i) {
+            const int idx = lane + 64 * i;
+            if (i < per_lane && idx < n) {
+                const float p = pitch[idx];
+                if (key_float(k[i]) >= thr && p > 0.0f) atomicAdd(&hist[tuning_bin(tuning_residual(p), sh.edges)], 1u);
+            }
+        }
+        wave_lds_sync();
+        // np.argmax: the first of the largest counts (two bins per lane; the key orders by count, then by smaller bin)
+        unsigned key = 0;
+        if (lane < 100) key = (hist[lane] << 8) | static_cast<unsigned>(255 - lane);
+        if (lane + 64 < 100) key = max(key, (hist[lane + 64] << 8) | static_cast<unsigned>(255 - (lane + 64)));
+        key = wave_max_bits(key);
+        tuning_idx = 255 - static_cast<int>(key & 255u);
+    }
+    if (lane == 0) {
+        sc.tuning_idx[seg] = tuning_idx;
+        if (tuning_out) tuning_out[sd.out_row] = static_cast<float>(tb.edges[tuning_idx]);
+    }
 }
 
 }  // namespace serhip

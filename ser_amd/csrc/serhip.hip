@@ -614,6 +614,10 @@ int launch_chunks(serhip_plan* plan, const CallPlan& cp, const Placement& pl, ch
             const dim3 segs_grid(static_cast<unsigned>(c.count));
             if (want_chroma || tuning_dev) {   // tuning estimate per segment (zeros when chroma is off)
                 LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream, timed);
+                if (want_chroma)   // one wave per segment for everything that fits its staging; the rest is left to the
+                                   // workgroup kernel below, which skips the segments already done
+                    hipLaunchKernelGGL(k_tuning_waves, dim3(static_cast<unsigned>((c.count + kTwWaves - 1) / kTwWaves)),
+                                       dim3(kTwWaves * 64), 0, stream, dd, static_cast<int>(c.count), plan->tb, sf, tuning_dev);
                 hipLaunchKernelGGL(k_segment_finish<1>, segs_grid, dim3(256), 0, stream, dd, plan->tb, sf, out_dev,
                                    tuning_dev, plan->dim);
             }
@@ -1458,6 +1462,8 @@ int serhip_tuning_from_peaks(serhip_plan* plan, const float* pitch_mag, const in
     float* d_tuning = reinterpret_cast<float*>(ws + head + lay.total);
     PlanTables tb = plan->tb;
     tb.flags |= SERHIP_FEAT_CHROMA;    // the estimate runs whatever the plan's flags
+    hipLaunchKernelGGL(k_tuning_waves, dim3(1), dim3(kTwWaves * 64), 0, nullptr, reinterpret_cast<const SegDesc*>(ws), 1, tb, sc,
+                       d_tuning);
     hipLaunchKernelGGL(k_segment_finish<1>, dim3(1), dim3(256), 0, nullptr, reinterpret_cast<const SegDesc*>(ws), tb, sc,
                        d_tuning, d_tuning, 0);
     HIP_TRY(hipGetLastError());
