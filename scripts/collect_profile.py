@@ -31,7 +31,7 @@ def main():
     keep, on = [], False
     for line in (src / "summary.txt").read_text().split("\n"):
         if not line.startswith(" "):
-            on = line.startswith(("k_stft", "k_project", "k_segment", "k_dft"))
+            on = line.startswith(("k_stft", "k_project", "k_segment", "k_tuning", "k_dft"))
         if on:
             keep.append(line)
     (dst / f"{tag}_summary.txt").write_text(

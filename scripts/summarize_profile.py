@@ -22,7 +22,7 @@ def short(name):
         m = re.search(key + r"<(\d)>", name) or re.search(key + r"ILi(\d)E", name)
         if m:
             return f"{key}<{m.group(1)}>"
-    for key in ("k_project_frames", "k_stft_frames", "k_segment_finish", "k_dft_frames", "k_pool_windows", "k_whisper_frames",
+    for key in ("k_project_frames", "k_stft_frames", "k_tuning_waves", "k_segment_finish", "k_dft_frames", "k_pool_windows", "k_whisper_frames",
                 "k_whisper_finalize", "k_prepare_normalise", "k_prepare_convert", "k_prepare_clip", "k_mlp_scale", "k_mlp_dense", "k_mlp_output"):
         if key in name:
             return key
