@@ -54,6 +54,9 @@ constexpr int kUnitFramesMax = 128;    // STFT frames per work unit of k_stft_fr
 constexpr int kBufC = 1088;            // complex slots of one wave's LDS buffer (16 rows x stride 68)
 constexpr int kGroups = 65;            // 16-bin groups covering bins 0..1039 (1025 used)
 constexpr int kPeakLdsCap = 2048;      // peaks staged in LDS by k_segment_finish
+// bit of PlanTables::flags set for ONE launch of k_segment_finish<1>: k_tuning_waves ran before it on the same
+// segments and sc.tuning_idx holds its results (>= 0) or -1 for the segments it left
+constexpr unsigned kFlagTuningWavesRan = 1u << 30;
 
 // per-segment descriptor (device copy of what the host planned)
 struct SegDesc {
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
     if constexpr (kMode == 1) {
         // k_tuning_waves ran first and took every segment whose peaks fit one wave's staging: what it left
         // (index -1: more than kTwPeakCap peaks or kTwFrameCap frames) is this kernel's
-        if (want_chroma && sc.tuning_idx[blockIdx.x] >= 0) return;
+        if (want_chroma && (tb.flags & kFlagTuningWavesRan) && sc.tuning_idx[blockIdx.x] >= 0) return;
     }
 
     // ---- mel mean and MFCC (power_to_db, top_db=80 vs the segment max, DCT of the time mean)
@@ -1301,6 +1304,10 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
 // to k_segment_finish<1>, which runs next and skips the segments done here), sc.seg_cmax[seg], tuning_out.
 // ---------------------------------------------------------------------------------------
 constexpr int kTwWaves = 4;
+// Calls with fewer segments than this go to k_segment_finish<1> alone: one wave working through a segment takes
+// twice as long as four waves sharing it (25 against 13 us), which is what a one-recording call waits for, and
+// only a batch that fills the chip several times over is bound by throughput instead.
+constexpr int kTwMinSegments = 2048;
 constexpr int kTwPeakCap = 1024;
 constexpr int kTwFrameCap = 1024;
 constexpr int kTwKeysPerLane = kTwPeakCap / 64;

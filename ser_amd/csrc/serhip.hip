@@ -614,11 +614,15 @@ int launch_chunks(serhip_plan* plan, const CallPlan& cp, const Placement& pl, ch
             const dim3 segs_grid(static_cast<unsigned>(c.count));
             if (want_chroma || tuning_dev) {   // tuning estimate per segment (zeros when chroma is off)
                 LaunchTimer lt(ctx, SERHIP_KERNEL_SEGMENT_FINISH, stream, timed);
-                if (want_chroma)   // one wave per segment for everything that fits its staging; the rest is left to the
-                                   // workgroup kernel below, which skips the segments already done
+                PlanTables tbl = plan->tb;
+                if (want_chroma && c.count >= kTwMinSegments) {
+                    // a large batch: one wave per segment for everything that fits a wave's staging; the rest is left
+                    // to the workgroup kernel below, which skips the segments already done
                     hipLaunchKernelGGL(k_tuning_waves, dim3(static_cast<unsigned>((c.count + kTwWaves - 1) / kTwWaves)),
                                        dim3(kTwWaves * 64), 0, stream, dd, static_cast<int>(c.count), plan->tb, sf, tuning_dev);
-                hipLaunchKernelGGL(k_segment_finish<1>, segs_grid, dim3(256), 0, stream, dd, plan->tb, sf, out_dev,
+                    tbl.flags |= kFlagTuningWavesRan;
+                }
+                hipLaunchKernelGGL(k_segment_finish<1>, segs_grid, dim3(256), 0, stream, dd, tbl, sf, out_dev,
                                    tuning_dev, plan->dim);
             }
             if (want_proj) {
@@ -1462,10 +1466,23 @@ int serhip_tuning_from_peaks(serhip_plan* plan, const float* pitch_mag, const in
     float* d_tuning = reinterpret_cast<float*>(ws + head + lay.total);
     PlanTables tb = plan->tb;
     tb.flags |= SERHIP_FEAT_CHROMA;    // the estimate runs whatever the plan's flags
-    hipLaunchKernelGGL(k_tuning_waves, dim3(1), dim3(kTwWaves * 64), 0, nullptr, reinterpret_cast<const SegDesc*>(ws), 1, tb, sc,
-                       d_tuning);
+    // both forms of the estimate, so that the known-answer tests drive both: first the workgroup kernel alone, then
+    // the wave kernel followed by the workgroup kernel for what it leaves; the answers must agree
+    float* d_both = d_tuning + 1;
     hipLaunchKernelGGL(k_segment_finish<1>, dim3(1), dim3(256), 0, nullptr, reinterpret_cast<const SegDesc*>(ws), tb, sc,
                        d_tuning, d_tuning, 0);
+    PlanTables tb2 = tb;
+    tb2.flags |= kFlagTuningWavesRan;
+    hipLaunchKernelGGL(k_tuning_waves, dim3(1), dim3(kTwWaves * 64), 0, nullptr, reinterpret_cast<const SegDesc*>(ws), 1, tb, sc,
+                       d_both);
+    hipLaunchKernelGGL(k_segment_finish<1>, dim3(1), dim3(256), 0, nullptr, reinterpret_cast<const SegDesc*>(ws), tb2, sc,
+                       d_both, d_both, 0);
+    HIP_TRY(hipGetLastError());
+    float both[2] = {0.0f, 0.0f};
+    HIP_TRY(hipMemcpy(both, d_tuning, sizeof(both), hipMemcpyDeviceToHost));
+    if (both[0] != both[1])
+        return fail(SERHIP_E_HIP, "serhip_tuning_from_peaks: k_segment_finish<1> and k_tuning_waves disagree (" +
+                                      std::to_string(both[0]) + " vs " + std::to_string(both[1]) + ")");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(tuning_out, d_tuning, sizeof(float), hipMemcpyDeviceToHost));
     return SERHIP_OK;

@@ -513,6 +513,38 @@ def _extract_in_worker(audio, sr):
     return HandcraftedBackend(feature_flags=FeatureFlags(tonnetz=False)).extract_vector(audio, sr)
 
 
+def test_wave_and_workgroup_tuning_kernels_agree_on_a_large_batch(engine, flags):
+    """Batches of 2 048 segments or more estimate the tuning with one wave per segment (``k_tuning_waves``), smaller
+    ones with one workgroup per segment (``k_segment_finish<1>``), and segments with more than 1 024 peaks fall back
+    to the latter inside a large batch: the same clips through one large call and through calls of 512 give the same
+    tuning estimates and the same feature bits.  (The small-batch form is the one the oracle tests pin.)"""
+    import torch
+
+    from ser_amd.synth import harmonic_clips_torch
+
+    n, length = 3072, 48000
+    audio = harmonic_clips_torch(77, n, length, engine.device)
+    gen = torch.Generator(device=engine.device).manual_seed(3)
+    noisy = torch.arange(0, n, 7, device=engine.device)                      # dense peaks: beyond one wave's staging
+    audio[noisy] += 0.3 * torch.randn((len(noisy), length), generator=gen, device=engine.device)
+    audio[5] = 0.0                                                            # no peaks at all
+    audio = audio.reshape(-1).contiguous()
+    rng = np.random.default_rng(9)
+    lens = rng.integers(2048, length + 1, n)
+    lens[:64] = length
+    offs = np.arange(n, dtype=np.int64) * length
+    big, big_t = engine.features(audio, offs, lens, 16000, flags, return_tuning=True)
+    parts, parts_t = [], []
+    for lo in range(0, n, 512):
+        f, t = engine.features(audio, offs[lo:lo + 512], lens[lo:lo + 512], 16000, flags, return_tuning=True)
+        parts.append(f)
+        parts_t.append(t)
+    small, small_t = torch.cat(parts), torch.cat(parts_t)
+    assert torch.equal(big_t, small_t)
+    assert torch.equal(big, small)
+    assert float(big_t[5]) == 0.0 and len(torch.unique(big_t)) > 20 and bool(torch.isfinite(big).all())
+
+
 def test_pooling_kernels_bit_exact(engine):
     """mean_std_pool / HandcraftedBackend.pool on the GPU equal numpy bit for bit."""
     from oracle import ser_fast_path as ofp
