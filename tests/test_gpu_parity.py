@@ -528,6 +528,7 @@ def test_wave_and_workgroup_tuning_kernels_agree_on_a_large_batch(engine, flags)
     noisy = torch.arange(0, n, 7, device=engine.device)                      # dense peaks: beyond one wave's staging
     audio[noisy] += 0.3 * torch.randn((len(noisy), length), generator=gen, device=engine.device)
     audio[5] = 0.0                                                            # no peaks at all
+    audio[torch.arange(3, n, 11, device=engine.device), : length // 3] *= 1e-5   # quiet stretches: tiles that top_db clips
     audio = audio.reshape(-1).contiguous()
     rng = np.random.default_rng(9)
     lens = rng.integers(2048, length + 1, n)
