@@ -328,6 +328,8 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
+            "parity": "features checked against oracle/ (numpy/scipy restatement of librosa 0.11) by tests/ -m gpu; parity with "
+                      "librosa itself is unpinned: the reference holds no numeric vector there and librosa is not installable here",
             "config": {
                 "workload": "config 3: 100k x 3 s clips @16 kHz sharded by utterance, 12 500 clips per GPU, "
                             "187-dim fast-profile features (mfcc40|chroma12|mel128|contrast7) + all-gather",
