@@ -650,19 +650,28 @@ def load_checked_partitions(*, train_utterances: Sequence, test_utterances: Sequ
                                                 audio_read_config=active.audio_read,
                                                 workers=_resolve_worker_count(active.num_cores, active.max_workers,
                                                                               len(jobs)))
-        rows, labels = [], []
-        for utterance, row, failure in zip(partition, matrix, failures):
-            if failure is not None:
-                if handle_sample_failure is not None and handle_sample_failure(utterance, failure):
+        # The reference walks the partition sample by sample (data_loader.py:495-526): a failed sample goes to the
+        # handler (True = skip it, otherwise its error is raised), a vector that is not finite raises the contract
+        # error.  Same decisions in the same order here, but only the samples that NEED a decision are visited one
+        # by one -- the finite test is one pass over the matrix and the kept rows are one mask, not 46 000 appends.
+        matrix = np.asarray(matrix, dtype=np.float64)
+        if matrix.ndim != 2 or matrix.shape[0] != len(partition):
+            raise ValueError("Fast feature contract failed: the feature matrix does not match the partition.")
+        failed = np.fromiter((f is not None for f in failures), dtype=bool, count=len(failures))
+        finite = np.isfinite(matrix).all(axis=1) if matrix.shape[1] > 0 else np.zeros(len(partition), dtype=bool)
+        keep = ~failed
+        for i in np.flatnonzero(failed | ~finite):
+            i = int(i)
+            if failed[i]:
+                if handle_sample_failure is not None and handle_sample_failure(partition[i], failures[i]):
                     continue
-                raise failure
-            if row.ndim != 1 or row.size <= 0 or not np.all(np.isfinite(row)):
-                raise ValueError(f"Fast feature contract failed for sample {utterance.sample_id!r}.")
-            rows.append(row)
-            labels.append(utterance.require_label())
-        if not rows:
+                raise failures[i]
+            raise ValueError(f"Fast feature contract failed for sample {partition[i].sample_id!r}.")
+        if not keep.any():
             raise RuntimeError("Fast checked preparation produced an empty split partition.")
-        return np.vstack(rows).astype(np.float64, copy=False), labels
+        if keep.all():
+            return matrix, [u.require_label() for u in partition]
+        return matrix[keep], [u.require_label() for u, k in zip(partition, keep.tolist()) if k]
 
     x_train, y_train = extract(train_utterances)
     x_test, y_test = extract(test_utterances)
