@@ -1484,14 +1484,23 @@ __global__ __launch_bounds__(kTwWaves * 64) void k_tuning_waves(const SegDesc* _
         hist[lane] = 0;
         hist[lane + 64] = 0;
         wave_lds_sync();
+        // the pitches of the peaks at or above the median (about half) are first compacted to the front of `pitch`
+        // (in place: round i writes below 64 i + 64, all of which has been read), so that the residuals -- a
+        // double-precision log2 each -- are evaluated with every lane busy
+        int n_pass = 0;
 #pragma unroll
         for (int i = 0; i < kTwKeysPerLane; ++i) {
-            const int idx = lane + 64 * i;
-            if (i < per_lane && idx < n) {
-                const float p = pitch[idx];
-                if (key_float(k[i]) >= thr && p > 0.0f) atomicAdd(&hist[tuning_bin(tuning_residual(p), sh.edges)], 1u);
+            if (i < per_lane) {
+                const int idx = lane + 64 * i;
+                const float p = idx < n ? pitch[idx] : 0.0f;
+                const bool pass = idx < n && key_float(k[i]) >= thr && p > 0.0f;
+                const unsigned long long mask = __ballot(pass);
+                if (pass) pitch[n_pass + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = p;
+                n_pass += __builtin_popcountll(mask);
             }
         }
+        wave_lds_sync();
+        for (int j = lane; j < n_pass; j += 64) atomicAdd(&hist[tuning_bin(tuning_residual(pitch[j]), sh.edges)], 1u);
         wave_lds_sync();
         // np.argmax: the first of the largest counts (two bins per lane; the key orders by count, then by smaller bin)
         unsigned key = 0;
