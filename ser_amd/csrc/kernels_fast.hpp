@@ -954,6 +954,19 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
     const int off_mel = off_chroma + (want_chroma ? kChroma : 0);
     const int off_contrast = off_mel + (want_mel ? kMels : 0);
     const int nbins = 1 + sd.n_fft / 2;
+    // kMode 2: this thread's first six values of the chroma time mean (a 3 s clip has six per thread) are requested now,
+    // so that their latency passes under the mel / MFCC reductions instead of after them
+    float chroma_pre[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (kMode == 2) {
+        if (want_chroma) {
+            const float* cn = sc.chroma_norm + static_cast<size_t>(sd.stft_base) * 16;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int t = (tid >> 4) + 16 * u;
+                if (t < sd.n_stft) chroma_pre[u] = cn[static_cast<size_t>(t) * 16 + (tid & 15)];
+            }
+        }
+    }
     if constexpr (kMode == 1) {
         // k_tuning_waves ran first and took every segment whose peaks fit one wave's staging: what it left
         // (index -1: more than kTwPeakCap peaks or kTwFrameCap frames) is this kernel's
@@ -968,10 +981,24 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         // rounding of the exact value; a float32 running sum here would not be)
         double s = 0.0;
         float lmax = -INFINITY;
+        // kMode 2: the dB minimum and dB sum of this thread's first four tiles (a 3 s clip has three per thread) are
+        // requested here, together with the power sums, instead of behind the floor and behind each other
+        float pre_min[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        double pre_sum[4] = {0.0, 0.0, 0.0, 0.0};
         if constexpr (kMode == 2) {
             // k_project_frames left dB values in `mel`, 16-frame power sums and per-tile dB maxima
             const int n_tiles = (sd.n_mel + 15) >> 4;
             const size_t tile0 = static_cast<size_t>(sd.mel_base) >> 4;
+            if (want_mfcc) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tl = half + 2 * u;
+                    if (tl < n_tiles) {
+                        pre_min[u] = sc.mel_dbmin[(tile0 + tl) * kMels + m];
+                        pre_sum[u] = sc.mel_dbsum[(tile0 + tl) * kMels + m];
+                    }
+                }
+            }
             for (int tl = half; tl < n_tiles; tl += 2) s += static_cast<double>(sc.mel_part[(tile0 + tl) * kMels + m]);
             for (int j = tid; j < n_tiles * 8; j += 256) lmax = fmaxf(lmax, sc.mel_dbmax[tile0 * 8 + j]);
         } else {
@@ -996,17 +1023,22 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
             if (want_mfcc) {
                 const int n_tiles = (sd.n_mel + 15) >> 4;
                 const size_t tile0 = static_cast<size_t>(sd.mel_base) >> 4;
-                for (int tl = half; tl < n_tiles; tl += 2) {
+                auto tile_sum = [&](int tl, float dbmin, double dbsum) {
+                    if (dbmin >= floor_db) return dbsum;
+                    double part = 0.0;
+                    const int t_end = min(16 * tl + 16, sd.n_mel);
+                    for (int t = 16 * tl; t < t_end; ++t)
+                        part += static_cast<double>(fmaxf(mel[static_cast<size_t>(t) * kMels + m], floor_db));
+                    return part;
+                };
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {          // the prefetched tiles, in the same order as before
+                    const int tl = half + 2 * u;
+                    if (tl < n_tiles) ls += tile_sum(tl, pre_min[u], pre_sum[u]);
+                }
+                for (int tl = half + 8; tl < n_tiles; tl += 2) {
                     const size_t at = (tile0 + tl) * kMels + m;
-                    if (sc.mel_dbmin[at] >= floor_db) {
-                        ls += sc.mel_dbsum[at];
-                    } else {
-                        double part = 0.0;
-                        const int t_end = min(16 * tl + 16, sd.n_mel);
-                        for (int t = 16 * tl; t < t_end; ++t)
-                            part += static_cast<double>(fmaxf(mel[static_cast<size_t>(t) * kMels + m], floor_db));
-                        ls += part;
-                    }
+                    ls += tile_sum(tl, sc.mel_dbmin[at], sc.mel_dbsum[at]);
                 }
             }
             sh.lsum[half][m] = ls;
@@ -1061,7 +1093,10 @@ __global__ __launch_bounds__(256, 2) void k_segment_finish(const SegDesc* __rest
         const int c = tid & 15, part = tid >> 4;
         const float* cn = sc.chroma_norm + static_cast<size_t>(sd.stft_base) * 16;
         float acc = 0.0f;
-        for (int t = part; t < sd.n_stft; t += 16) acc += cn[static_cast<size_t>(t) * 16 + c];
+#pragma unroll
+        for (int u = 0; u < 6; ++u)                                   // requested at the top of the kernel
+            if (part + 16 * u < sd.n_stft) acc += chroma_pre[u];
+        for (int t = part + 96; t < sd.n_stft; t += 16) acc += cn[static_cast<size_t>(t) * 16 + c];
         __syncthreads();
         float* slots = reinterpret_cast<float*>(sh.melsum);   // 256 floats fit in melsum (2 x 128 doubles)
         slots[part * 16 + c] = acc;
