@@ -370,10 +370,14 @@ def _group_config_error(feature_flags: FeatureFlags, rate: int) -> Exception | N
 
 def featurize_audio_jobs_device(jobs: Sequence[tuple[str, float | None, float | None]], *,
                                 feature_flags: FeatureFlags, audio_read_config: AudioReadConfig, workers: int = 8,
-                                device_prepare: bool = True, pipelined: bool | None = None, stats: dict | None = None):
+                                device_prepare: bool = True, pipelined: bool | None = None, stats: dict | None = None,
+                                to_host: bool = False):
     """Device-resident form of :func:`featurize_audio_jobs`: ``(matrix, errors)`` with ``matrix`` a
     ``[n_jobs, D]`` float32 torch tensor on the engine's GPU (failed rows NaN).  The multi-GPU gather
     takes this tensor as it is -- features never visit the host on their way into the collective.
+
+    ``to_host=True`` returns the matrix as the reference's float64 numpy array instead (widened on the device:
+    exact); the pipelined form sends each slab's rows back while later slabs are still in flight.
 
     ``pipelined`` (default: on with ``device_prepare``, off with ``SERHIP_INGEST=sequential``): files are read by
     ``workers`` native threads straight into pinned memory one slab ahead, each slab's raw bytes travel on a copy
@@ -390,7 +394,7 @@ def featurize_audio_jobs_device(jobs: Sequence[tuple[str, float | None, float | 
     matrix = torch.full((n, dim), float("nan"), dtype=torch.float32, device=engine.device)
     errors: list[Exception | None] = [None] * n
     if n == 0 or dim == 0:
-        return matrix, errors
+        return (np.full((n, dim), np.nan, dtype=np.float64) if to_host else matrix), errors
     if pipelined is None:
         pipelined = device_prepare and os.environ.get("SERHIP_INGEST", "pipelined") != "sequential"
 
@@ -414,10 +418,13 @@ def featurize_audio_jobs_device(jobs: Sequence[tuple[str, float | None, float | 
     if pipelined:
         from .ingest import featurize_jobs_pipelined
 
-        featurize_jobs_pipelined(
+        host = np.empty((n, dim), dtype=np.float64) if to_host else None
+        sent = featurize_jobs_pipelined(
             jobs, feature_flags=feature_flags, audio_read_config=audio_read_config, workers=workers, matrix=matrix,
             errors=errors, read_fallback=lambda job: _read_one((*job, audio_read_config, False)),
-            run_host_group=run_host_members, bisect=_bisecting, stats=stats)
+            run_host_group=run_host_members, bisect=_bisecting, stats=stats, host_out=host)
+        if to_host:
+            return (host if sent else engine.to_host_float64(matrix)), errors
         return matrix, errors
 
     for lo, hi in _job_slabs(jobs, _slab_bytes()):
@@ -456,7 +463,7 @@ def featurize_audio_jobs_device(jobs: Sequence[tuple[str, float | None, float | 
         for rate, members in host_groups.items():
             run_host_members(lo, rate, members)
         del decoded
-    return matrix, errors
+    return (engine.to_host_float64(matrix) if to_host else matrix), errors
 
 
 def featurize_audio_jobs(jobs: Sequence[tuple[str, float | None, float | None]], *, feature_flags: FeatureFlags,
@@ -472,13 +479,12 @@ def featurize_audio_jobs(jobs: Sequence[tuple[str, float | None, float | None]],
     require_accelerated(feature_flags)
     if len(jobs) == 0 or feature_flags.width() == 0:
         return np.full((len(jobs), feature_flags.width()), np.nan, dtype=np.float64), [None] * len(jobs)
-    matrix, errors = featurize_audio_jobs_device(jobs, feature_flags=feature_flags,
-                                                 audio_read_config=audio_read_config, workers=workers,
-                                                 device_prepare=device_prepare)
     # widened on the device (exact), so that the host sees the API's float64 without a pass of its own
-    from .engine import get_engine
+    return featurize_audio_jobs_device(jobs, feature_flags=feature_flags, audio_read_config=audio_read_config,
+                                       workers=workers, device_prepare=device_prepare, to_host=True)
 
-    return get_engine(matrix.device.index).to_host_float64(matrix), errors
+
+_device_loader = featurize_audio_jobs_device   # (what featurize_files may ask for ``to_host``; a replacement is not asked)
 
 
 def featurize_files(files: Sequence[str], *, settings=None, distributed: bool = False, featurize_jobs=None):
@@ -497,8 +503,9 @@ def featurize_files(files: Sequence[str], *, settings=None, distributed: bool = 
     run = featurize_jobs if featurize_jobs is not None else featurize_audio_jobs_device
     if not distributed:
         workers = _resolve_worker_count(active.num_cores, active.max_workers, len(files))
+        to_host = {"to_host": True} if run is _device_loader else {}   # (a replacement keeps the documented signature)
         matrix, errors = run([(f, None, None) for f in files], feature_flags=active.feature_flags,
-                             audio_read_config=active.audio_read, workers=workers)
+                             audio_read_config=active.audio_read, workers=workers, **to_host)
         if hasattr(matrix, "is_cuda") and matrix.is_cuda:
             from .engine import get_engine
 

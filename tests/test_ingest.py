@@ -243,6 +243,48 @@ def test_pipelined_loader_overlaps_and_reuses_its_buffers(tmp_path, monkeypatch)
 
 
 @pytest.mark.gpu
+def test_pipelined_loader_sends_rows_to_the_host_slab_by_slab(tmp_path, monkeypatch):
+    """``to_host=True``: the float64 numpy matrix assembled from per-slab copies on the way (``ingest._RowsToHost``)
+    is the widened device matrix -- failed rows NaN, host-decoded rows in place, a smaller second call through the
+    kept pinned landing area, a result over the limit through the end-of-call copy."""
+    from ser_amd import AudioReadConfig, FeatureFlags, ingest
+    from ser_amd.data_loader import featurize_audio_jobs, featurize_audio_jobs_device
+
+    rng = np.random.default_rng(29)
+    jobs = _dataset(tmp_path, rng, n=30)
+    bad_dir = tmp_path / "bad"
+    bad_dir.mkdir()
+    bad = _corpus(bad_dir, rng)
+    jobs = jobs[:11] + bad[:4] + jobs[11:] + bad[4:]
+    flags = FeatureFlags(tonnetz=False)
+    cfg = AudioReadConfig(max_retries=1, retry_delay_seconds=0.0)
+    monkeypatch.setenv("SERHIP_SLAB_BYTES", str(1 << 20))
+    dev, dev_err = featurize_audio_jobs_device(jobs, feature_flags=flags, audio_read_config=cfg, workers=4, pipelined=False)
+    want = dev.double().cpu().numpy()
+    assert np.isnan(want).any() and np.isfinite(want).any()
+    for subset in (len(jobs), 9, len(jobs)):
+        stats = {}
+        got, errs = featurize_audio_jobs_device(jobs[:subset], feature_flags=flags, audio_read_config=cfg, workers=4,
+                                                pipelined=True, stats=stats, to_host=True)
+        assert isinstance(got, np.ndarray) and got.dtype == np.float64 and got.flags.c_contiguous and got.flags.writeable
+        assert stats["slabs"] >= (2 if subset > 9 else 1)
+        assert np.array_equal(got, want[:subset], equal_nan=True)
+        assert [type(e) for e in errs] == [type(e) for e in dev_err[:subset]]
+    # the sequential form and the public wrapper give the same array
+    seq, _ = featurize_audio_jobs_device(jobs, feature_flags=flags, audio_read_config=cfg, workers=4, pipelined=False, to_host=True)
+    assert np.array_equal(seq, want, equal_nan=True)
+    pub, _ = featurize_audio_jobs(jobs, feature_flags=flags, audio_read_config=cfg, workers=4)
+    assert np.array_equal(pub, want, equal_nan=True)
+    # over the limit: no landing area is made for it, the matrix comes back after the call
+    monkeypatch.setattr(ingest, "ROWS_TO_HOST_LIMIT", 1024)
+    big, _ = featurize_audio_jobs_device(jobs, feature_flags=flags, audio_read_config=cfg, workers=4, pipelined=True, to_host=True)
+    assert np.array_equal(big, want, equal_nan=True)
+    # nothing to do
+    none, errs = featurize_audio_jobs_device([], feature_flags=flags, audio_read_config=cfg, to_host=True)
+    assert none.shape == (0, 187) and none.dtype == np.float64 and errs == []
+
+
+@pytest.mark.gpu
 def test_pipelined_loader_with_nothing_readable(tmp_path):
     """Every file missing: per-file FileNotFoundError, NaN rows, no exception from the slab machinery (a slab of zero bytes)."""
     import torch
