@@ -300,6 +300,16 @@ int serhip_flac_decode(const void* bytes, int64_t n_bytes, int32_t* out, int64_t
  * no counterpart: its arrays never leave the host). */
 int serhip_parallel_memcpy(void* dst, const void* src, int64_t bytes, int threads);
 
+/* The same team gathering `n_arrays` float32 arrays (array i: `src_len[i]` floats at `src[i]`, a host address passed
+ * as an integer) into one buffer -- array i lands at `dst + dst_offset[i]` floats; regions must lie inside
+ * [0, dst_len) and are the caller's to keep apart -- and checking, in the same pass over the bytes, that every sample
+ * is finite: `*all_finite` = 1, or 0 when a NaN or an infinity was copied (the copy is complete either way).
+ * Replaces, for a batch of clips held as separate numpy arrays, the per-clip `np.isfinite(...).all()` of the
+ * reference's input validation (ser/_internal/utils/dsp.py:93-95) and the `np.concatenate` a batched call would
+ * otherwise need: neither pass over the samples remains on the host. */
+int serhip_gather_f32(const uint64_t* src, const int64_t* src_len, const int64_t* dst_offset, int64_t n_arrays, float* dst,
+                      int64_t dst_len, int threads, int32_t* all_finite);
+
 /* ---- host-only helpers (no GPU touched; used by the CPU test-suite) ---- */
 
 /* Copy one host-built constant table of the fast plan into `out` (f32).

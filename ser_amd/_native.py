@@ -64,6 +64,7 @@ SIGNATURES: dict[str, tuple] = {
     ),
     "serhip_stat_files": (c_int, [c_void_p, POINTER(c_int64), c_int64, c_int, POINTER(c_int64)]),
     "serhip_parallel_memcpy": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "serhip_gather_f32": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), c_int64, c_void_p, c_int64, c_int, POINTER(c_int32)]),
     "serhip_flac_probe": (c_int, [c_void_p, c_int64, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
     "serhip_flac_decode": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, POINTER(c_int64)]),
     "serhip_host_table": (c_int64, [c_int, c_int, c_int, POINTER(c_float), c_int64]),

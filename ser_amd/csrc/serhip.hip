@@ -1589,6 +1589,51 @@ int serhip_parallel_memcpy(void* dst, const void* src, int64_t bytes, int thread
     return SERHIP_OK;
 }
 
+int serhip_gather_f32(const uint64_t* src, const int64_t* src_len, const int64_t* dst_offset, int64_t n_arrays, float* dst,
+                      int64_t dst_len, int threads, int32_t* all_finite) {
+    if (n_arrays < 0 || dst_len < 0) return fail(SERHIP_E_INVALID, "serhip_gather_f32: negative count");
+    if (!all_finite) return fail(SERHIP_E_INVALID, "serhip_gather_f32: all_finite is NULL");
+    *all_finite = 1;
+    if (n_arrays == 0) return SERHIP_OK;
+    if (!src || !src_len || !dst_offset || !dst) return fail(SERHIP_E_INVALID, "serhip_gather_f32: NULL argument");
+    // work items: pieces of at most 1 Mi floats, so that one hour-long array is shared by the team as 12 500 clips are
+    constexpr int64_t kPiece = 1 << 20;
+    struct Item {
+        int64_t array, at, count;
+    };
+    std::vector<Item> items;
+    items.reserve(static_cast<size_t>(n_arrays));
+    for (int64_t i = 0; i < n_arrays; ++i) {
+        if (src_len[i] < 0 || dst_offset[i] < 0 || dst_offset[i] > dst_len - src_len[i])
+            return fail(SERHIP_E_INVALID, "serhip_gather_f32: region of array " + std::to_string(i) + " lies outside dst");
+        if (src_len[i] > 0 && src[i] == 0) return fail(SERHIP_E_INVALID, "serhip_gather_f32: array " + std::to_string(i) + " is NULL");
+        for (int64_t at = 0; at < src_len[i]; at += kPiece) items.push_back({i, at, std::min(kPiece, src_len[i] - at)});
+    }
+    std::atomic<uint32_t> bad{0};
+    parallel_for(static_cast<int64_t>(items.size()), threads, [&](int64_t k) {
+        const Item& it = items[static_cast<size_t>(k)];
+        const float* from = reinterpret_cast<const float*>(static_cast<uintptr_t>(src[it.array])) + it.at;
+        float* to = dst + dst_offset[it.array] + it.at;
+        // copy and test block by block: the block just copied is still in this core's cache when it is tested
+        constexpr int64_t kBlock = 8192;
+        uint32_t seen = 0;
+        for (int64_t b = 0; b < it.count; b += kBlock) {
+            const int64_t m = std::min(kBlock, it.count - b);
+            std::memcpy(to + b, from + b, static_cast<size_t>(m) * sizeof(float));
+            uint32_t word;
+            uint32_t acc = 0;
+            for (int64_t j = 0; j < m; ++j) {   // exponent all ones = NaN or infinity
+                std::memcpy(&word, from + b + j, sizeof(word));
+                acc |= static_cast<uint32_t>((word & 0x7f800000u) == 0x7f800000u);
+            }
+            seen |= acc;
+        }
+        if (seen) bad.store(1, std::memory_order_relaxed);
+    });
+    if (bad.load()) *all_finite = 0;
+    return SERHIP_OK;
+}
+
 int serhip_flac_probe(const void* bytes, int64_t n_bytes, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample,
                       int64_t* total_frames) {
     if (!bytes || n_bytes < 0) return fail(SERHIP_E_INVALID, "serhip_flac_probe: NULL or negative-length input");

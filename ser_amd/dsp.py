@@ -26,8 +26,16 @@ class ParameterError(Exception):
     """Counterpart of ``librosa.util.exceptions.ParameterError`` raised through dsp.py:129."""
 
 
-def validate_signal(audio: NDArray[np.float32], sample_rate: int) -> NDArray[np.float32]:
-    """Input checks of dsp.py:85-95, in the reference's order; returns a float32 view/copy."""
+def samples_all_finite(prepared: NDArray[np.float32]) -> bool:
+    """A finite sum of squares proves every sample finite (NaN and inf propagate) in one BLAS pass without the
+    boolean temporary of np.isfinite; an overflowing one falls through to the exact test."""
+    return bool(np.isfinite(np.dot(prepared, prepared))) or bool(np.all(np.isfinite(prepared)))
+
+
+def validate_signal(audio: NDArray[np.float32], sample_rate: int, *, finite_check: bool = True) -> NDArray[np.float32]:
+    """Input checks of dsp.py:85-95, in the reference's order; returns a float32 view/copy.  ``finite_check=False``
+    leaves the last of them (every sample finite) to the caller, who passes ``check_finite=True`` to
+    ``FeatureEngine.features``: the staging threads then test the samples in the pass that copies them."""
     if sample_rate <= 0:
         raise ValueError("Sample rate must be a positive integer.")
     if audio.ndim != 1:
@@ -35,9 +43,7 @@ def validate_signal(audio: NDArray[np.float32], sample_rate: int) -> NDArray[np.
     if audio.size == 0:
         raise ValueError("Audio contains no samples.")
     prepared = np.asarray(audio, dtype=np.float32)
-    # a finite sum of squares proves every sample finite (NaN and inf propagate) in one BLAS pass without
-    # the boolean temporary of np.isfinite; an overflowing one falls through to the exact test
-    if not np.isfinite(np.dot(prepared, prepared)) and not bool(np.all(np.isfinite(prepared))):
+    if finite_check and not samples_all_finite(prepared):
         raise ValueError("Audio buffer is not finite everywhere.")
     return prepared
 

@@ -170,7 +170,7 @@ class FeatureEngine:
     STREAM_FROM_HOST_BYTES = 32 << 20
 
     def features(self, audio, seg_offset, seg_len, sample_rate: int, flags: FeatureFlags, *,
-                 return_tuning: bool = False, out=None):
+                 return_tuning: bool = False, out=None, check_finite: bool = False):
         """Feature matrix ``[n_seg, D]`` (float32, on device) for segments of ``audio``.
 
         ``audio`` is a 1-D float32 numpy array or torch tensor (moved to the GPU if
@@ -178,6 +178,9 @@ class FeatureEngine:
         contiguous float32 ``[n_seg, D]`` device tensor (e.g. a row range of a larger matrix) the kernels
         write into.  A large numpy buffer whose segments come in non-decreasing order is not copied whole
         first: it is staged chunk by chunk while the kernels run (``ingest.features_from_host``).
+        ``check_finite`` (numpy ``audio`` only): raise the reference's ``ValueError`` when a sample of the buffer is
+        not finite (dsp.py:93-95) -- tested by the staging threads as they copy on the staged path, by one BLAS pass
+        (``dsp.samples_all_finite``) otherwise.
         """
         require_accelerated(flags)
         torch = self._torch
@@ -195,7 +198,12 @@ class FeatureEngine:
                 and bool((np.diff(off) >= 0).all())):
             from .ingest import features_from_host
 
-            return features_from_host(self, audio, off, length, int(sample_rate), flags, out=out)
+            return features_from_host(self, audio, off, length, int(sample_rate), flags, out=out, check_finite=check_finite)
+        if check_finite and isinstance(audio, np.ndarray):
+            from .dsp import samples_all_finite
+
+            if not samples_all_finite(np.asarray(audio, dtype=np.float32)):
+                raise ValueError("Audio buffer is not finite everywhere.")
         audio_dev = self.to_device(audio)
         if audio_dev.dim() != 1:
             raise ValueError("audio must be a 1-D sample buffer")

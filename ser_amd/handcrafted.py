@@ -12,13 +12,14 @@ across many recordings (the dataset featurisation loop of
 
 from __future__ import annotations
 
+import os
 from collections.abc import Sequence
 
 import numpy as np
 from numpy.typing import NDArray
 
 from . import dsp
-from .engine import get_engine
+from .engine import FeatureEngine, get_engine
 from .types import (
     EncodedSequence,
     FeatureFlags,
@@ -37,6 +38,16 @@ def sliding_window_bounds(n_samples: int, sample_rate: int, size_seconds, stride
     starts = np.arange(0, n_samples, frame_step, dtype=np.int64)
     ends = np.minimum(starts + frame_length, n_samples)
     return starts, ends
+
+
+def _at_least(arrays, nbytes: int) -> bool:
+    """Do the arrays hold ``nbytes`` or more between them?  (Stops counting as soon as they do.)"""
+    total = 0
+    for a in arrays:
+        total += getattr(a, "nbytes", 0)
+        if total >= nbytes:
+            return True
+    return False
 
 
 class HandcraftedBackend:
@@ -135,10 +146,28 @@ class HandcraftedBackend:
     # ------------------------------------------------------------------ batches
     def extract_vectors(self, audios: Sequence[NDArray[np.float32]], sample_rate: int) -> FeatureMatrix:
         """``[len(audios), D]`` float64: one vector per whole clip, one GPU batch for all clips."""
+        dim = self._feature_flags.width()
+        if (dim and len(audios) > 1 and os.environ.get("SERHIP_INGEST", "pipelined") != "sequential"
+                and _at_least(audios, FeatureEngine.STREAM_FROM_HOST_BYTES)):
+            # a large batch: the clips are neither concatenated nor tested for non-finite samples on the host -- the
+            # staging threads gather them chunk by chunk and test them in the same pass (ingest.features_from_host_arrays)
+            from .ingest import features_from_host_arrays
+
+            if sample_rate <= 0:
+                raise ValueError("Sample rate must be a positive integer.")
+            for a in audios:   # validate_signal's shape checks, inline: 12 500 calls of it cost 12 ms
+                if a.ndim != 1:
+                    raise ValueError("Audio must be mono (1D array).")
+                if a.size == 0:
+                    raise ValueError("Audio contains no samples.")
+            require_accelerated(self._feature_flags)
+            dsp.check_flags_for_rate(self._feature_flags, sample_rate)
+            engine = get_engine()
+            return engine.to_host_float64(features_from_host_arrays(engine, audios, sample_rate, self._feature_flags))
         prepared = [dsp.validate_signal(a, sample_rate) for a in audios]
         require_accelerated(self._feature_flags)
-        if self._feature_flags.width() == 0 or not prepared:
-            return np.empty((len(prepared), self._feature_flags.width()), dtype=np.float64)
+        if dim == 0 or not prepared:
+            return np.empty((len(prepared), dim), dtype=np.float64)
         dsp.check_flags_for_rate(self._feature_flags, sample_rate)
         lengths = np.asarray([a.size for a in prepared], dtype=np.int64)
         offsets = np.concatenate(([0], np.cumsum(lengths)[:-1])).astype(np.int64)
@@ -151,12 +180,17 @@ class HandcraftedBackend:
         if sample_rate <= 0:
             raise ValueError("sample_rate must be a positive integer.")
         prepared, bounds = [], []
+        dim = self._feature_flags.width()
+        # one long recording: its samples are tested for NaN / infinity by the threads that stage them for the GPU
+        # (engine.features(check_finite=True)), not by a pass over the buffer in front of everything else
+        defer = (len(audios) == 1 and dim > 0 and isinstance(audios[0], np.ndarray)
+                 and audios[0].nbytes >= FeatureEngine.STREAM_FROM_HOST_BYTES)
         for audio in audios:
             if audio.ndim != 1:
                 raise ValueError("audio must be mono (1D array).")
             if audio.size == 0:
                 raise ValueError("audio must contain at least one sample.")
-            a = dsp.validate_signal(audio, sample_rate)
+            a = dsp.validate_signal(audio, sample_rate, finite_check=not defer)
             prepared.append(a)
             bounds.append(sliding_window_bounds(a.size, sample_rate, self._frame_size_seconds,
                                                 self._frame_stride_seconds))
@@ -167,10 +201,10 @@ class HandcraftedBackend:
         base = np.concatenate(([0], np.cumsum([a.size for a in prepared])[:-1])).astype(np.int64)
         offsets = np.concatenate([b + s for b, (s, _) in zip(base, bounds)])
         lengths = np.concatenate([e - s for s, e in bounds])
-        dim = self._feature_flags.width()
         if dim:
             packed = prepared[0] if len(prepared) == 1 else np.concatenate(prepared)
-            emb = get_engine().features(packed, offsets, lengths, sample_rate, self._feature_flags).cpu().numpy()
+            emb = get_engine().features(packed, offsets, lengths, sample_rate, self._feature_flags,
+                                        check_finite=defer).cpu().numpy()
         else:
             emb = np.empty((offsets.size, 0), dtype=np.float32)
         result, row = [], 0

@@ -117,6 +117,45 @@ def test_parallel_memcpy_and_slab_plan(native_lib):
     assert blob == b"a\0bcd\0\xc3\xa9f\0" and offsets.tolist() == [0, 2, 6]
 
 
+def test_gather_copies_arrays_and_finds_non_finite_samples(native_lib):
+    """``serhip_gather_f32``: many small arrays, an array longer than one work item, empty arrays, NaN / infinity at the
+    first and last sample of a piece and of a test block; regions outside the destination are refused."""
+    from ser_amd import _native, ingest
+
+    rng = np.random.default_rng(31)
+    lens = [0, 1, 7, 8191, 8192, 8193, 48000, (1 << 20) + 5, 3, 0, (2 << 20) + 8192]
+    arrays = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    off = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64) + 3     # three floats of slack in front
+    dst = np.full(int(sum(lens)) + 5, -7.0, dtype=np.float32)
+
+    def run(threads):
+        dst[:] = -7.0
+        ptrs = np.asarray([a.ctypes.data if a.size else 0 for a in arrays], dtype=np.uint64)
+        return ingest.gather_f32(dst.ctypes.data, dst.size, ptrs, np.asarray(lens), off, threads)
+
+    for threads in (1, 5):
+        assert run(threads) is True
+        assert np.array_equal(dst[3:-2], np.concatenate(arrays)) and (dst[:3] == -7.0).all() and (dst[-2:] == -7.0).all()
+    for which, at, value in ((1, 0, np.nan), (4, 8191, np.inf), (5, 8192, -np.inf), (7, 1 << 20, np.nan), (7, (1 << 20) - 1, np.inf),
+                             (10, (2 << 20) + 8191, np.nan), (6, 17, np.float32(np.nan))):
+        keep = arrays[which][at]
+        arrays[which][at] = value
+        assert run(4) is False, (which, at)
+        assert np.array_equal(dst[3:-2], np.concatenate(arrays), equal_nan=True)   # the copy is complete either way
+        arrays[which][at] = keep
+    assert run(4) is True
+    # the largest finite value and denormals are finite
+    arrays[2][:3] = [np.finfo(np.float32).max, np.finfo(np.float32).tiny / 4, -0.0]
+    assert run(3) is True
+    with pytest.raises(_native.SerhipError, match="outside dst"):
+        ingest.gather_f32(dst.ctypes.data, 10, np.asarray([arrays[3].ctypes.data], dtype=np.uint64), np.asarray([8191]), np.asarray([4]))
+    with pytest.raises(_native.SerhipError, match="outside dst"):
+        ingest.gather_f32(dst.ctypes.data, dst.size, np.asarray([arrays[3].ctypes.data], dtype=np.uint64), np.asarray([8191]), np.asarray([-1]))
+    with pytest.raises(_native.SerhipError, match="NULL"):
+        ingest.gather_f32(dst.ctypes.data, dst.size, np.asarray([0], dtype=np.uint64), np.asarray([4]), np.asarray([0]))
+    assert ingest.gather_f32(dst.ctypes.data, dst.size, np.zeros(0, dtype=np.uint64), np.zeros(0), np.zeros(0)) is True
+
+
 def test_bisect_raises_device_and_config_errors_at_once():
     """only per-clip / size-dependent failures are bisected."""
     from ser_amd._native import SerhipError
@@ -324,6 +363,90 @@ def test_host_buffer_streams_in_chunks_with_the_whole_buffer_result():
         np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
     with pytest.raises(ValueError, match="outside the audio buffer"):
         features_from_host(eng, audio, np.array([audio.size - 10]), np.array([48000]), 16000, flags)
+
+
+@pytest.mark.gpu
+def test_host_clips_are_gathered_and_checked_by_the_staging_threads(monkeypatch):
+    """Clips held as separate numpy arrays (``HandcraftedBackend.extract_vectors`` on a large batch) and one long
+    recording (``encode_sequence``): no concatenation and no finite test on the host, same bits as the plain path, the
+    reference's ValueError for a NaN or an infinity wherever it sits."""
+    import torch
+
+    from ser_amd import FeatureFlags, HandcraftedBackend
+    from ser_amd.engine import FeatureEngine, get_engine
+    from ser_amd.ingest import features_from_host, features_from_host_arrays
+    from ser_amd.synth import harmonic_clips
+
+    eng = get_engine()
+    flags = FeatureFlags(tonnetz=False)
+    rng = np.random.default_rng(37)
+    base = harmonic_clips(rng, 40, 48000, 16000)
+    lens = rng.integers(3000, 48000, 40)
+    clips = [np.ascontiguousarray(base[i, : lens[i]]) for i in range(40)]
+    clips[3] = clips[3].astype(np.float64)                  # converted on the way
+    clips[5] = np.repeat(clips[5], 2)[::2]                  # a strided view
+    clips[8] = clips[8][:700]                               # the generic (n_fft < 2048) path
+    packed = np.concatenate([np.asarray(c, dtype=np.float32) for c in clips])
+    sizes = np.asarray([c.size for c in clips], dtype=np.int64)
+    offs = np.cumsum(sizes) - sizes
+    want = eng.features(torch.from_numpy(packed).to(eng.device), offs, sizes, 16000, flags).cpu().numpy()
+    for chunk_bytes in (1 << 20, 64 << 20):
+        stats = {}
+        got = features_from_host_arrays(eng, clips, 16000, flags, chunk_bytes=chunk_bytes, stats=stats)
+        assert stats["chunks"] >= (4 if chunk_bytes == 1 << 20 else 1)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    for which, at, value in ((0, 0, np.nan), (17, 100, np.inf), (39, -1, -np.inf), (3, 5, 1e300)):   # 1e300 is inf as float32
+        keep = clips[which][at]
+        clips[which][at] = value
+        with np.errstate(over="ignore"), pytest.raises(ValueError, match="not finite everywhere"):
+            features_from_host_arrays(eng, clips, 16000, flags, chunk_bytes=1 << 20)
+        clips[which][at] = keep
+    np.testing.assert_array_equal(features_from_host_arrays(eng, clips, 16000, flags).cpu().numpy(), want)   # and usable again
+    with pytest.raises(ValueError, match="no samples"):
+        features_from_host_arrays(eng, clips[:2] + [np.zeros(0, dtype=np.float32)], 16000, flags)
+
+    # the backend: a batch over the threshold takes this path, and returns what the concatenating path returns
+    backend = HandcraftedBackend(feature_flags=flags)
+    monkeypatch.setenv("SERHIP_INGEST", "sequential")
+    plain = backend.extract_vectors(clips, 16000)
+    monkeypatch.delenv("SERHIP_INGEST")
+    monkeypatch.setattr(FeatureEngine, "STREAM_FROM_HOST_BYTES", 1 << 16)
+    staged = backend.extract_vectors(clips, 16000)
+    assert staged.dtype == np.float64 and np.array_equal(staged, plain) and np.array_equal(staged, want.astype(np.float64))
+    clips[11][7] = np.nan
+    with pytest.raises(ValueError, match="not finite everywhere"):
+        backend.extract_vectors(clips, 16000)
+    clips[11][7] = 0.0
+    with pytest.raises(ValueError, match="mono"):
+        backend.extract_vectors(clips[:4] + [np.zeros((2, 2000), dtype=np.float32)], 16000)
+
+    # one long recording: windows by descriptor, the finite test rides on the staging copy
+    recording = np.ascontiguousarray(base[:12].reshape(-1))
+    seq_plain_env = {"SERHIP_INGEST": "sequential"}
+    monkeypatch.setenv("SERHIP_INGEST", "sequential")
+    enc_plain = backend.encode_sequence(recording, 16000)
+    monkeypatch.delenv("SERHIP_INGEST")
+    enc = backend.encode_sequence(recording, 16000)
+    assert np.array_equal(enc.embeddings, enc_plain.embeddings) and np.array_equal(enc.frame_start_seconds, enc_plain.frame_start_seconds)
+    for at in (0, recording.size // 2, recording.size - 1):
+        keep = recording[at]
+        recording[at] = np.inf
+        with pytest.raises(ValueError, match="not finite everywhere"):
+            backend.encode_sequence(recording, 16000)
+        recording[at] = keep
+    # a stretch no window covers (segments that leave a gap and a tail) is tested too
+    off2 = np.asarray([0, 48000, 200000], dtype=np.int64)
+    len2 = np.asarray([48000, 48000, 48000], dtype=np.int64)
+    ok = features_from_host(eng, recording, off2, len2, 16000, flags, check_finite=True, chunk_bytes=1 << 20)
+    np.testing.assert_array_equal(ok.cpu().numpy(), eng.features(torch.from_numpy(recording).to(eng.device), off2, len2, 16000, flags).cpu().numpy())
+    for at in (150000, recording.size - 5):
+        keep = recording[at]
+        recording[at] = np.nan
+        with pytest.raises(ValueError, match="not finite everywhere"):
+            features_from_host(eng, recording, off2, len2, 16000, flags, check_finite=True, chunk_bytes=1 << 20)
+        features_from_host(eng, recording, off2, len2, 16000, flags, chunk_bytes=1 << 20)   # not asked: not tested
+        recording[at] = keep
+    del seq_plain_env
 
 
 @pytest.mark.gpu
