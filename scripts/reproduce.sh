@@ -24,7 +24,7 @@ case "$MODE" in
     grep -E "^k_" "gpurun_out/prof_$TAG/summary.txt"
     bash scripts/profile_configs.sh "$TAG" > "gpurun_out/prof_configs_$TAG.log" 2>&1 || { tail -5 "gpurun_out/prof_configs_$TAG.log"; exit 1; }
     tail -12 "gpurun_out/prof_configs_$TAG.log"
-    timeout -k 10 400 python scripts/bench_configs.py --only config4_host_api,config4_from_file,config2_from_files,config2_from_files_x4,config3_from_host \
+    timeout -k 10 400 python scripts/bench_configs.py --only config4_host_api,config4_from_file,config2_from_files,config2_from_files_x4,config3_from_host,config3_backend_api \
         --out "gpurun_out/ingest_$TAG.json" 2> "gpurun_out/ingest_$TAG.err"
     ( cd /tmp && TMPDIR=/tmp timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv \
         -d "$OLDPWD/gpurun_out/ingest_trace_$TAG" -- python3 "$OLDPWD/scripts/ingest_trace.py" > "$OLDPWD/gpurun_out/ingest_trace_$TAG.log" 2>&1 )

@@ -541,6 +541,15 @@ def features_from_host(engine, audio: np.ndarray, seg_offset: np.ndarray, seg_le
                                    threads=threads, stats=stats, check_finite=check_finite)
 
 
+def _chunk_bytes_for(total_bytes: int) -> int:
+    """Staging chunk size for a host buffer of ``total_bytes``: ``SERHIP_CHUNK_BYTES`` when set, else the default capped
+    at a sixteenth of the buffer (not below 8 MiB) -- the first chunk's staging and the last chunk's kernels overlap
+    with nothing, and an hour of audio (230 MB) in four 64 MiB chunks spends a quarter of its time in them."""
+    if os.environ.get("SERHIP_CHUNK_BYTES"):
+        return _env_bytes("SERHIP_CHUNK_BYTES", DEFAULT_CHUNK_BYTES)
+    return max(8 << 20, min(DEFAULT_CHUNK_BYTES, -(-int(total_bytes) // 16)))
+
+
 def _run_staged_chunks(engine, chunks, largest_floats: int, stage_into, sample_rate: int, flags, off, length, out) -> None:
     """The loop both host-buffer pipelines share.  ``chunks``: ``[(i0, i1, a, b)]`` -- segments ``[i0, i1)`` live in
     samples ``[a, b)`` of the (virtual) packed buffer; ``stage_into(k, pinned_ptr)`` fills the pinned staging of chunk
@@ -588,7 +597,7 @@ def _features_from_host(engine, audio: np.ndarray, seg_offset: np.ndarray, seg_l
         return out
     if (off < 0).any() or (length < 1).any() or int((off + length).max()) > audio.shape[0]:
         raise ValueError("a segment is empty or lies outside the audio buffer")
-    chunk_bytes = chunk_bytes or _env_bytes("SERHIP_CHUNK_BYTES", DEFAULT_CHUNK_BYTES)
+    chunk_bytes = chunk_bytes or _chunk_bytes_for(audio.nbytes)
     # chunks of consecutive segments: [first sample of the first, furthest end among them) must fit a staging buffer
     ends = np.maximum.accumulate(off + length)
     chunks, i = [], 0
@@ -646,7 +655,7 @@ def features_from_host_arrays(engine, arrays, sample_rate: int, flags, *, out=No
             raise ValueError("Audio contains no samples.")
         ends = np.cumsum(length)
         off = ends - length
-        chunk_bytes = chunk_bytes or _env_bytes("SERHIP_CHUNK_BYTES", DEFAULT_CHUNK_BYTES)
+        chunk_bytes = chunk_bytes or _chunk_bytes_for(int(ends[-1]) * 4)
         chunks, i, limit = [], 0, chunk_bytes // 4
         while i < n_seg:
             j = max(int(np.searchsorted(ends, off[i] + limit, side="right")), i + 1)
