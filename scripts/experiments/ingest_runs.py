@@ -1,5 +1,6 @@
 """Per-run clocks of the pipelined loader on the config-2-from-files corpus (11 520 x reps/60 files): where does a slow
-run spend its time?  Usage: python scripts/experiments/ingest_runs.py [reps] [runs]"""
+run spend its time?  Usage: python scripts/experiments/ingest_runs.py [reps] [runs]
+EXP_PROFILE=1: a cProfile of one more call (main thread only) behind the runs, top entries by own time."""
 import os, sys, time, tempfile, shutil, gc
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scripts"))
@@ -37,5 +38,14 @@ try:
         t3 = time.perf_counter()
         print(f"run {r}: call {1e3*(t1-t0):.1f} sync {1e3*(t2-t1):.1f} to_host {1e3*(t3-t2):.1f} | " +
               " ".join(f"{k[:-2]} {1e3*v:.1f}" for k, v in stats.items() if isinstance(v, float)), flush=True)
+    if os.environ.get("EXP_PROFILE"):
+        import cProfile, io, pstats
+        prof = cProfile.Profile()
+        prof.enable()
+        featurize_audio_jobs_device(jobs, feature_flags=FLAGS, audio_read_config=cfg, workers=threads, pipelined=True, to_host=True)
+        prof.disable()
+        out = io.StringIO()
+        pstats.Stats(prof, stream=out).sort_stats("tottime").print_stats(40)
+        print(out.getvalue())
 finally:
     shutil.rmtree(root, ignore_errors=True)
