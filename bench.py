@@ -119,9 +119,10 @@ def cpu_baseline(n_clips: int, workers: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 200 steps of ~3.6 ms = a timed region of ~0.7 s (long enough for an outside sampler of GPU activity to
-    # see it, and for the mean to sit within the box-to-box spread rather than within one step's jitter)
-    ap.add_argument("--steps", type=int, default=200)
+    # defaults: 1 000 steps of ~3.3 ms = a timed region of ~3.3 s (long enough for an outside sampler of GPU activity
+    # that looks every few seconds to see it, and for the mean to sit within the box-to-box spread rather than within
+    # one step's jitter; 5 steps measured a clock ramp, 200 steps were still shorter than the CPU baseline's import)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips-per-gpu", type=int, default=CLIPS_PER_GPU)
     ap.add_argument("--cpu-clips", type=int, default=4000, help="clips in the CPU baseline sample (0 = skip)")
