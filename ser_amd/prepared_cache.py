@@ -20,16 +20,26 @@ compressed ``.npz`` (``np.savez_compressed``), no pickled objects, replaced atom
 reference's reader additionally checks the file against its digest-protected plan ledger
 (governance, out of scope); here ``feature_dtype`` / ``feature_shape`` stand in for the plan.
 
+The writer produces the same container -- a zip archive of deflated ``.npy`` members that ``np.load`` and the
+reference's reader open -- but deflates it with a team of threads (:func:`write_npz_deflated`): ``np.savez_compressed``
+is one thread of zlib at level 6, 12 s for the 69 MB float64 matrix of a 46 080-file corpus that the GPU featurises
+in 62 ms.
+
 The module is table-driven: :data:`SCHEMA` lists the entries once and both directions walk it.
 """
 
 from __future__ import annotations
 
 import contextlib
+import io
 import json
 import os
+import struct
 import tempfile
+import time
+import zlib
 from collections.abc import Mapping, Sequence
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import NamedTuple
 
@@ -103,6 +113,93 @@ def _replacing(destination: Path):
         raise
 
 
+#: bytes of a member deflated as one independent piece (pieces are joined at full-flush points into ONE deflate stream)
+DEFLATE_PIECE_BYTES = 1 << 20
+#: zlib level of the payload file: 1 (23 MB/s and thread, 0.60 of the size on float32 values widened to float64) where
+#: numpy's writer uses 6 (5.6 MB/s, 0.55); ``SERHIP_CACHE_DEFLATE_LEVEL`` overrides
+DEFAULT_DEFLATE_LEVEL = 1
+_ZIP32_LIMIT = 0xFFFFFFFF
+
+
+def _deflate_threads() -> int:
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:  # pragma: no cover
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def _npy_pieces(arr: np.ndarray, piece_bytes: int) -> list:
+    """The bytes of ``np.save(arr)`` as a list of buffers of at most ``piece_bytes`` (the header rides in front of the
+    first one); a large matrix is sliced in place, never copied."""
+    arr = np.asarray(arr)
+    if arr.dtype.hasobject:
+        raise ValueError("object arrays are not written (no pickles in a payload file)")
+    if arr.ndim == 0 or arr.dtype.kind in "US" or arr.nbytes <= piece_bytes or not arr.flags.c_contiguous:
+        buf = io.BytesIO()
+        np.lib.format.write_array(buf, arr, allow_pickle=False)   # (numpy's own layout choices: Fortran order is kept)
+        whole = memoryview(buf.getvalue())
+        return [whole[i:i + piece_bytes] for i in range(0, max(1, len(whole)), piece_bytes)]
+    head = io.BytesIO()
+    np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(arr))
+    data = memoryview(arr).cast("B")
+    first = piece_bytes - len(head.getvalue()) % piece_bytes
+    pieces = [head.getvalue() + bytes(data[:first])]
+    pieces += [data[i:i + piece_bytes] for i in range(first, len(data), piece_bytes)]
+    return pieces
+
+
+def write_npz_deflated(handle, arrays: Mapping[str, np.ndarray], *, level: int | None = None, threads: int | None = None,
+                       piece_bytes: int | None = None) -> None:
+    """``np.savez_compressed(handle, **arrays)`` with the deflating done by ``threads`` threads: every member's ``.npy``
+    image is cut into pieces, each piece is deflated on its own (zlib releases the GIL) and ended with a full flush, and
+    the pieces in order ARE one raw deflate stream -- the member any zip reader expects.  CRC-32 of each member runs
+    beside the deflating.  Members or archives of 4 GiB and more (zip64) are left to ``np.savez_compressed`` itself."""
+    if level is None:
+        level = int(os.environ.get("SERHIP_CACHE_DEFLATE_LEVEL", DEFAULT_DEFLATE_LEVEL))
+    piece_bytes = int(piece_bytes or DEFLATE_PIECE_BYTES)
+    threads = int(threads or _deflate_threads())
+    prepared = {name: np.asarray(value) for name, value in arrays.items()}
+    if sum(a.nbytes for a in prepared.values()) + 4096 * len(prepared) >= _ZIP32_LIMIT or len(prepared) >= 0xFFFF:
+        np.savez_compressed(handle, **prepared)
+        return
+    members = [(f"{name}.npy".encode("utf-8"), _npy_pieces(arr, piece_bytes)) for name, arr in prepared.items()]
+
+    def deflate(job):
+        piece, last = job
+        comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+        return comp.compress(piece) + comp.flush(zlib.Z_FINISH if last else zlib.Z_FULL_FLUSH)
+
+    def checksum(pieces):
+        crc = 0
+        for piece in pieces:
+            crc = zlib.crc32(piece, crc)
+        return crc & 0xFFFFFFFF
+
+    now = time.localtime()
+    dos_date = (max(now.tm_year, 1980) - 1980) << 9 | now.tm_mon << 5 | now.tm_mday
+    dos_time = now.tm_hour << 11 | now.tm_min << 5 | now.tm_sec // 2
+    directory = []
+    start = handle.tell()
+    with ThreadPoolExecutor(max_workers=threads, thread_name_prefix="serhip-deflate") as team:
+        crcs = [team.submit(checksum, pieces) for _, pieces in members]
+        streams = [team.map(deflate, [(piece, k == len(pieces) - 1) for k, piece in enumerate(pieces)]) for _, pieces in members]
+        for (name, pieces), crc_job, stream in zip(members, crcs, streams):
+            deflated = list(stream)
+            crc = crc_job.result()
+            c_size, u_size, at = sum(map(len, deflated)), sum(map(len, pieces)), handle.tell() - start
+            fixed = struct.pack("<HHHHHIIIHH", 20, 0, 8, dos_time, dos_date, crc, c_size, u_size, len(name), 0)
+            handle.write(b"PK\x03\x04" + fixed + name)
+            for block in deflated:
+                handle.write(block)
+            directory.append(b"PK\x01\x02" + struct.pack("<H", 20 | 3 << 8) + fixed + struct.pack("<HHHII", 0, 0, 0, 0o600 << 16, at)
+                             + name)
+    dir_at = handle.tell() - start
+    for entry in directory:
+        handle.write(entry)
+    dir_size = handle.tell() - start - dir_at
+    handle.write(b"PK\x05\x06" + struct.pack("<HHHHIIH", 0, 0, len(directory), len(directory), dir_size, dir_at, 0))
+
+
 def default_prepared_payload_path(settings) -> Path:
     """Where the reference publishes the fast profile's payload: ``settings.tmp_folder /
     "prepared-training-fast.npz"`` (training_readiness.py:880-882 with the profile name this package
@@ -125,7 +222,7 @@ def write_prepared_feature_payload(path=None, *, settings=None, x_train, x_dev, 
     arrays = {name: _encode(kind, given[name]) for name, kind in SCHEMA}
     destination = Path(path) if path is not None else default_prepared_payload_path(settings)
     with _replacing(destination) as handle:
-        np.savez_compressed(handle, **arrays)
+        write_npz_deflated(handle, arrays)   # the container of np.savez_compressed, deflated by a team of threads
     return destination
 
 

@@ -1,5 +1,7 @@
 """Dataset loader host logic and the prepared-feature cache container (CPU) + the GPU loader run."""
 
+import json
+
 import numpy as np
 import pytest
 
@@ -108,6 +110,57 @@ def test_prepared_cache_round_trip_and_validation(tmp_path):
     with pytest.raises(TypeError, match="Unsupported prepared metadata type"):
         write_prepared_feature_payload(tmp_path / "m.npz", x_train=xs[0], x_dev=xs[1], x_test=xs[2], y_train=ys[0],
                                        y_dev=ys[1], y_test=ys[2], metadata={"x": object()})
+
+
+def test_payload_file_is_the_container_numpy_writes(tmp_path, monkeypatch):
+    """``write_npz_deflated`` (members deflated piece by piece on a team of threads): any zip reader accepts the file
+    (CRCs, sizes, directory), ``np.load`` returns the arrays ``np.savez_compressed`` would have stored -- dtype, shape and
+    bits --, for pieces much smaller than a member, a member that is exactly a multiple of the piece size, empty
+    matrices, unicode labels and the 0-d JSON string; zip64-sized archives are left to numpy's own writer."""
+    import io
+    import zipfile
+
+    from ser_amd import prepared_cache as pc
+
+    rng = np.random.default_rng(41)
+    arrays = {"x_train": rng.standard_normal((513, 187)).astype(np.float32).astype(np.float64), "x_dev": np.zeros((0, 187)),
+              "x_test": rng.standard_normal((3, 187)), "y_train": np.asarray([f"e{i % 8}" for i in range(513)], dtype=np.str_),
+              "y_dev": np.asarray([], dtype=np.str_), "y_test": np.asarray(["a", "é", "c"]), "metadata_json": np.asarray('{"a":1}'),
+              "ints": np.arange(10, dtype=np.int32).reshape(2, 5), "fortran": np.asfortranarray(rng.standard_normal((300, 7))),
+              "exact": np.zeros(4096 - 128 // 8 * 0, dtype=np.uint8)}
+    want_buf = io.BytesIO()
+    np.savez_compressed(want_buf, **arrays)
+    want_buf.seek(0)
+    want = np.load(want_buf, allow_pickle=False)
+    for piece, threads, level in ((4096, 3, 1), (1000, 1, 6), (1 << 20, 8, None)):
+        buf = io.BytesIO()
+        buf.write(b"")   # (the archive starts where the handle stands)
+        pc.write_npz_deflated(buf, arrays, piece_bytes=piece, threads=threads, level=level)
+        buf.seek(0)
+        with zipfile.ZipFile(buf) as z:
+            assert z.testzip() is None
+            assert z.namelist() == [f"{k}.npy" for k in arrays]
+            assert all(i.compress_type == zipfile.ZIP_DEFLATED for i in z.infolist())
+        buf.seek(0)
+        got = np.load(buf, allow_pickle=False)
+        assert set(got.files) == set(arrays)
+        for k in arrays:
+            assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape and np.array_equal(got[k], want[k]), (k, piece)
+            assert got[k].flags.f_contiguous == want[k].flags.f_contiguous, k
+    with pytest.raises(ValueError, match="object arrays"):
+        pc.write_npz_deflated(io.BytesIO(), {"o": np.asarray([{"a": 1}], dtype=object)})
+    # the published file goes through it, and a plain numpy reader opens it
+    path = pc.write_prepared_feature_payload(tmp_path / "p.npz", x_train=arrays["x_train"], x_dev=arrays["x_dev"], x_test=arrays["x_test"],
+                                             y_train=arrays["y_train"], y_dev=[], y_test=["a", "b", "c"], metadata={"k": [1, 2]})
+    with np.load(path, allow_pickle=False) as z:
+        assert np.array_equal(z["x_train"], arrays["x_train"]) and json.loads(str(z["metadata_json"][()])) == {"k": [1, 2]}
+    assert pc.read_prepared_feature_payload(path, feature_shape=(516, 187)).y_test == ["a", "b", "c"]
+    # an archive that would need zip64: numpy's writer is called instead
+    called = {}
+    monkeypatch.setattr(pc, "_ZIP32_LIMIT", 1000)
+    monkeypatch.setattr(pc.np, "savez_compressed", lambda handle, **kw: called.update(kw))
+    pc.write_npz_deflated(io.BytesIO(), {"x": arrays["x_train"]})
+    assert list(called) == ["x"]
 
 
 def test_prepared_cache_writer_takes_the_references_keywords(tmp_path):
