@@ -47,5 +47,18 @@ try:
         out = io.StringIO()
         pstats.Stats(prof, stream=out).sort_stats("tottime").print_stats(40)
         print(out.getvalue())
+    if os.environ.get("EXP_LOAD_DATA"):   # the reference-shaped entry point on the same corpus, profiled
+        import cProfile, io, pstats
+        from ser_amd.data_loader import LoaderSettings, load_data
+        settings = LoaderSettings(dataset_folder=root, feature_flags=FLAGS, max_workers=threads, num_cores=threads)
+        for _ in range(2):
+            t0 = time.perf_counter(); load_data(settings=settings); print(f"load_data {1e3*(time.perf_counter()-t0):.1f} ms", flush=True)
+        prof = cProfile.Profile()
+        prof.enable()
+        load_data(settings=settings)
+        prof.disable()
+        out = io.StringIO()
+        pstats.Stats(prof, stream=out).sort_stats("cumulative").print_stats(45)
+        print(out.getvalue())
 finally:
     shutil.rmtree(root, ignore_errors=True)

@@ -596,15 +596,21 @@ def load_data(test_size: float | None = None, *, settings=None) -> DataSplit | N
     if len(set(labels)) < 2:
         logger.warning("At least two emotion classes are required to train the model.")
         return None
-    features = np.asarray(rows, dtype=np.float64)
+    features = np.ascontiguousarray(rows, dtype=np.float64)
+    # train_test_split(features, labels, ...) of the reference (data_loader.py:425-444) -- which rows go where depends
+    # on the row count, the labels and the seed only, so the split is drawn on row numbers and the two halves of the
+    # matrix are copied by the memcpy team instead of by sklearn's single-threaded fancy indexing (same rows, same order)
+    order = np.arange(features.shape[0])
     try:
-        split = train_test_split(features, labels, test_size=resolved_test_size, random_state=active.random_state,
+        split = train_test_split(order, labels, test_size=resolved_test_size, random_state=active.random_state,
                                  stratify=labels if active.stratify_split else None)
     except ValueError as err:
         logger.warning("Stratified split failed (%s). Falling back to non-stratified split.", err)
-        split = train_test_split(features, labels, test_size=resolved_test_size, random_state=active.random_state,
+        split = train_test_split(order, labels, test_size=resolved_test_size, random_state=active.random_state,
                                  stratify=None)
-    return (np.asarray(split[0], dtype=np.float64), np.asarray(split[1], dtype=np.float64),
+    from .ingest import take_rows
+
+    return (take_rows(features, split[0]), take_rows(features, split[1]),
             [str(v) for v in split[2]], [str(v) for v in split[3]])
 
 

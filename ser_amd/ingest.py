@@ -204,6 +204,32 @@ def gather_f32(dst_ptr: int, dst_len: int, src_ptr: np.ndarray, src_len: np.ndar
     return bool(finite.value)
 
 
+#: row selections at least this large are copied by the memcpy team (below that numpy's own take is as fast)
+TAKE_ROWS_TEAM_BYTES = 8 << 20
+
+
+def take_rows(matrix: np.ndarray, index: np.ndarray, threads: int | None = None) -> np.ndarray:
+    """``matrix[index]`` for a C-contiguous float64 ``[n, D]`` matrix and an integer index vector: the rows are copied
+    by the memcpy team (``serhip_gather_f32`` on the rows' addresses; a float64 row travels as 2 D words and the call's
+    finite verdict is not used) -- the train / test halves of a 46 080-row split are 69 MB of fancy indexing, 45 ms on
+    one thread."""
+    index = np.asarray(index)
+    if (matrix.dtype != np.float64 or matrix.ndim != 2 or not matrix.flags.c_contiguous or index.ndim != 1
+            or index.dtype.kind not in "iu" or index.size * matrix.shape[1] * 8 < TAKE_ROWS_TEAM_BYTES):
+        return matrix[index]
+    index = index.astype(np.int64, copy=False)
+    n, dim = matrix.shape
+    if index.size and (int(index.min()) < -n or int(index.max()) >= n):
+        raise IndexError("take_rows: index out of range")
+    index = np.where(index < 0, index + n, index)
+    out = np.empty((index.size, dim), dtype=np.float64)
+    words = 2 * dim
+    src = (np.uint64(matrix.ctypes.data) + index.astype(np.uint64) * np.uint64(8 * dim)).astype(np.uint64)
+    gather_f32(out.ctypes.data, out.size * 2, src, np.full(index.size, words, dtype=np.int64),
+               np.arange(index.size, dtype=np.int64) * words, threads)
+    return out
+
+
 def plan_slabs(sizes: np.ndarray, slab_bytes: int, follows: np.ndarray | None = None) -> list[tuple[int, int]]:
     """Cut ``range(len(sizes))`` into consecutive ``[lo, hi)`` slabs whose 16-byte-aligned file sizes add up to at
     most ``slab_bytes`` (a single larger file gets a slab of its own).  Missing files (-1) take no room: they fail

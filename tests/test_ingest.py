@@ -156,6 +156,30 @@ def test_gather_copies_arrays_and_finds_non_finite_samples(native_lib):
     assert ingest.gather_f32(dst.ctypes.data, dst.size, np.zeros(0, dtype=np.uint64), np.zeros(0), np.zeros(0)) is True
 
 
+def test_take_rows_is_fancy_indexing(native_lib, monkeypatch):
+    """``ingest.take_rows`` (the two halves of a train / test split copied by the memcpy team) returns ``matrix[index]``:
+    permutations, repeats, negative indices, empty selections; anything it is not built for goes to numpy itself."""
+    from ser_amd import ingest
+
+    rng = np.random.default_rng(43)
+    m = rng.standard_normal((5000, 187))
+    m[17, 3] = np.nan           # a failed row travels like any other
+    monkeypatch.setattr(ingest, "TAKE_ROWS_TEAM_BYTES", 1)
+    for index in (rng.permutation(5000)[:3750], np.asarray([0, 0, 4999, -1, -5000, 17]), np.zeros(0, dtype=np.int64),
+                  rng.integers(0, 5000, 9000).astype(np.int32)):
+        got = ingest.take_rows(m, index, threads=3)
+        assert got.flags.c_contiguous and got.flags.owndata and np.array_equal(got, m[index], equal_nan=True)
+    with pytest.raises(IndexError):
+        ingest.take_rows(m, np.asarray([5000]))
+    with pytest.raises(IndexError):
+        ingest.take_rows(m, np.asarray([-5001]))
+    assert np.array_equal(ingest.take_rows(m.astype(np.float32), np.asarray([1, 2])), m.astype(np.float32)[[1, 2]])   # numpy's path
+    assert np.array_equal(ingest.take_rows(m[:, ::2], np.asarray([1, 2])), m[:, ::2][[1, 2]])
+    mask = np.zeros(5000, dtype=bool)
+    mask[[4, 9]] = True
+    assert np.array_equal(ingest.take_rows(m, mask), m[mask])
+
+
 def test_bisect_raises_device_and_config_errors_at_once():
     """only per-clip / size-dependent failures are bisected."""
     from ser_amd._native import SerhipError
