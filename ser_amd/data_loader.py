@@ -291,6 +291,22 @@ def _job_slabs(jobs, budget: int):
         yield first, len(jobs)
 
 
+def _rows_where(matrix: np.ndarray, test) -> np.ndarray:
+    """Rows of a float matrix in which ``test`` (``np.isnan`` or "not finite") holds somewhere, without a boolean
+    temporary the size of the matrix: NaN and infinity propagate into the row's sum, so only rows whose SUM is not
+    finite are looked at element by element (that also clears a row of finite values whose sum overflowed)."""
+    with np.errstate(over="ignore", invalid="ignore"):
+        sums = matrix.sum(axis=1)
+    hit = np.zeros(matrix.shape[0], dtype=bool)
+    for i in np.flatnonzero(~np.isfinite(sums)):
+        hit[i] = bool(test(matrix[i]).any())
+    return hit
+
+
+def _not_finite(values: np.ndarray) -> np.ndarray:
+    return ~np.isfinite(values)
+
+
 def _is_batch_fatal(err: Exception) -> bool:
     """Errors that halving a batch cannot cure and that must not be dressed up as per-file failures: a HIP runtime
     failure reported by the library (``SERHIP_E_HIP``; after a device fault every later call fails the same way),
@@ -541,7 +557,7 @@ def featurize_files(files: Sequence[str], *, settings=None, distributed: bool = 
         full = full.numpy().astype(np.float64)
     errors: list[Exception | None] = [None] * len(files)
     owner = np.searchsorted(bounds, np.arange(len(files)), side="right") - 1
-    for i in np.flatnonzero(np.isnan(full).any(axis=1)):
+    for i in np.flatnonzero(_rows_where(full, np.isnan)):
         i = int(i)
         errors[i] = local_err[i - lo] if lo <= i < hi else RuntimeError(
             f"feature extraction of {files[i]} failed on rank {int(owner[i])}")
@@ -671,7 +687,7 @@ def load_checked_partitions(*, train_utterances: Sequence, test_utterances: Sequ
         if matrix.ndim != 2 or matrix.shape[0] != len(partition):
             raise ValueError("Fast feature contract failed: the feature matrix does not match the partition.")
         failed = np.fromiter((f is not None for f in failures), dtype=bool, count=len(failures))
-        finite = np.isfinite(matrix).all(axis=1) if matrix.shape[1] > 0 else np.zeros(len(partition), dtype=bool)
+        finite = ~_rows_where(matrix, _not_finite) if matrix.shape[1] > 0 else np.zeros(len(partition), dtype=bool)
         keep = ~failed
         for i in np.flatnonzero(failed | ~finite):
             i = int(i)
