@@ -477,6 +477,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             }
         }
         wave_lds_sync();
+        __builtin_amdgcn_s_setprio(1);   // (frame_priority below)
         K1_STAMP(2)
 
         // ---- stage B: 16-pt DFT over m1, twiddle W_64^(m2*j1), radix-4 across the quad
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         }
         if (lane == 0) sM[512] = m512;
         wave_lds_sync();
+        __builtin_amdgcn_s_setprio(3);
         K1_STAMP(5)
 
         // ---- the segment's largest magnitude bounds its mel power from above: k_project_frames uses it to tell
@@ -668,6 +670,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
             for (int i = 0; i < kStoreBlock; ++i) *slot = 0;   // volatile: kStoreBlock separate store instructions
         }
     }
+    // frame_priority: a wave raises its issue priority as it moves through a frame -- 0 for the window and stage A,
+    // 1 from stage B, 2 from the unpack (the next frame's loads go out first thing there), 3 for the peak scan and the
+    // store block, back to 0 for the next frame.  The four waves of a SIMD are at different points of their frames;
+    // letting the one that is furthest along issue first gets its vector-memory operations (the longest latencies of
+    // the frame) out earliest and frees its LDS buffer soonest.  Measured round robin in one call against the
+    // arbiter's default (oldest wave first): 1.874 -> 1.820 ms per 12 500 clips (-2.9 %); the reverse grading
+    // (young frames first) 1.91 ms; high priority for the transform alone +0.6 %, for the finish alone -0.9 %.
     while (more) {
         const int t = wu.t_begin + (pos - base);
         const size_t row = static_cast<size_t>(sd.stft_base) + static_cast<size_t>(t);
@@ -679,11 +688,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_stft_frames(const float* __rest
         wait_samples<kStoreBlock>();
         fix_padded_frame(t, v);
         transform_frame(v, win);
+        __builtin_amdgcn_s_setprio(2);
         finish_frame(row, seg, [&]() {
             pos = __builtin_amdgcn_readfirstlane(drawn);
             more = seek();
             if (more) load_frame_async(wu.t_begin + (pos - base), v);
         });
+        __builtin_amdgcn_s_setprio(0);
         K1_STAMP(8)
 #if SERHIP_K1_STAMPS
         ++stamp_frames;

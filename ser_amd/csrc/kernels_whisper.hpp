@@ -87,6 +87,10 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
     float* p = s_p[wave];
     float vmax = -INFINITY;
 
+    // Issue priority rises as a wave moves through its frame (0 framing, 1 first DFT stage, 2 second stage, 3 unpack /
+    // mel / log) and falls back for the next one: of the four waves of a SIMD the one furthest along goes first, so a
+    // frame's chain of six LDS-synchronised stages is not stretched by waves that have only just started theirs
+    // (64 x 30 s clips: 0.372-0.386 -> 0.344-0.348 ms, round robin in one call; same idea as k_stft_frames).
     for (int f = wave; f < kWTile; f += kWWaves) {
         const int t = t_tile + f;
         if (t >= n_frames) break;
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
             }
         }
         wave_lds_sync();
+        __builtin_amdgcn_s_setprio(1);
         // ---- step 1: Y[k1][n2] = sum_{n1<25} z[8 n1 + n2] W_25^(n1 k1), then * W_200^(n2 k1): eight 25-point
         // DFTs (one per n2), each as 5 x 5 Cooley-Tukey with n1 = 5 p + q, k1 = r + 5 s.  Lane (n2, q) takes
         // the 5-point DFT over p and the twiddle W_25^(q r); lane (n2, r) then the 5-point DFT over q.
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
             }
         }
         wave_lds_sync();
+        __builtin_amdgcn_s_setprio(2);
         // ---- step 2: Z[k1 + 25 k2] = sum_{n2<8} Y'[k1][n2] W_8^(n2 k2): lane k1 < 25 reads its eight values
         // (128 contiguous bytes) and takes a radix-2 x radix-4 FFT in registers (~60 operations; the
         // 8-term sums with constant roots took 112 on each of 50 lanes).  z was last read in step 1.
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
             }
         }
         wave_lds_sync();
+        __builtin_amdgcn_s_setprio(3);
         // ---- real-FFT unpack to bins 0..200 and |X|^2
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(kWWaves * 64) void k_whisper_frames(const float* __
             }
         }
         wave_lds_sync();
+        __builtin_amdgcn_s_setprio(0);
     }
     vmax = wave_max(vmax);
     if (lane == 0) s_red[wave] = vmax;
