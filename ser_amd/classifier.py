@@ -104,7 +104,7 @@ class GpuEmotionClassifier:
         else:
             arr = np.asarray(features)
             arr = arr.astype(np.float64 if arr.dtype != np.float32 else np.float32, copy=False)
-            x = torch.from_numpy(np.ascontiguousarray(arr)).to(eng.device)
+            x = eng.to_device_staged(np.ascontiguousarray(arr))   # a large matrix goes through the pinned ring
         if x.dim() != 2 or int(x.shape[1]) != self.n_features_in_:
             raise ValueError(
                 f"X has {tuple(x.shape)[1] if x.dim() == 2 else '?'} features, but the classifier "

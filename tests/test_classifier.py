@@ -132,6 +132,11 @@ def test_gpu_classifier_matches_sklearn(n_classes, hidden, activation, scaler):
     assert gpu.predict_proba(x[:0]).shape == (0, n_classes)
     with pytest.raises(ValueError, match="features"):
         gpu.predict(x[:, :-1])
+    # a matrix large enough for the staged upload (pinned ring, memcpy team): the same labels and probabilities
+    big = np.tile(x, (-(-12000 // len(x)), 1))[:12000]
+    assert big.nbytes >= gpu._engine.STAGED_TO_HOST_BYTES
+    np.testing.assert_array_equal(gpu.predict(big)[: len(x)], model.predict(x))
+    np.testing.assert_array_equal(gpu.predict_proba(big)[: len(x)], gpu.predict_proba(x))
 
 
 @pytest.mark.gpu

@@ -496,6 +496,15 @@ def test_staged_matrix_to_host_equals_the_plain_copy(monkeypatch):
     monkeypatch.setattr(FeatureEngine, "STAGED_CHUNK_BYTES", (1 << 20) + 4096)
     m = torch.randn((30011, 187), generator=gen, device=eng.device)
     assert np.array_equal(eng.to_host_float64(m), m.double().cpu().numpy())
+    # and the other direction (FeatureEngine.to_device_staged: what the classifier's batch predict uploads with)
+    rng = np.random.default_rng(6)
+    for shape, dtype in (((30011, 187), np.float64), ((7001, 187), np.float32), ((3, 5), np.float64), ((0, 187), np.float64),
+                         ((1 << 20) + 3, np.int16)):
+        a = (rng.standard_normal(shape) * 100).astype(dtype)
+        dev = eng.to_device_staged(a)
+        assert dev.device == eng.device and tuple(dev.shape) == a.shape and np.array_equal(dev.cpu().numpy(), a)
+    strided = rng.standard_normal((9000, 374))[:, ::2]
+    assert np.array_equal(eng.to_device_staged(strided).cpu().numpy(), strided)
 
 
 @pytest.mark.gpu
